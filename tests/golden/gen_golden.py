@@ -1,0 +1,262 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by running the REAL reference.
+
+Runs ONLY in the build container (needs /root/reference, which never travels to the GPU
+box).  It imports the reference's own modules -- clip/model.py (L1) and
+trainers/mm_classifier_one_prompt.py (L2) -- feeds them the seeded synthetic weights and
+inputs of ovmr_amd/synth.py, and records their outputs as small .npz fixtures.  Nothing
+from the reference (source, bytecode, vocabulary) is copied into this repository: the
+fixtures hold only inputs that cannot be regenerated (token ids the reference tokenizer
+produced for a few class names) and the reference's numeric outputs.
+
+Harness: the reference imports torchvision / ftfy / torcheval /
+dassl, none of which exist offline, and calls .cuda() unconditionally.  We install
+name-only stubs for those modules and make .cuda() the identity.  torcheval's
+multiclass_f1_score is the one stub that carries arithmetic; it is restated from
+torcheval 0.0.7's published algorithm (argmax -> tp/n_pred/n_label -> 2pr/(p+r) ->
+nan_to_num), see oracle/ovmr_oracle.py:multiclass_f1_per_class.
+
+Usage:  PYTHONDONTWRITEBYTECODE=1 python tests/golden/gen_golden.py [--only tiny|vitb16|tok]
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import sys
+import tempfile
+import types
+from types import SimpleNamespace
+
+sys.dont_write_bytecode = True
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+REF = os.environ.get("OVMR_REFERENCE", "/root/reference")
+sys.path.insert(0, REPO)
+
+from ovmr_amd import synth  # noqa: E402
+
+
+# ----------------------------------------------------------------------------- harness
+def _f1_stub(input, target, *, num_classes=None, average="micro"):
+    assert average is None
+    pred = input.argmax(dim=1)
+    target = target.long()
+    tp = torch.bincount(target[pred == target], minlength=num_classes).float()
+    n_label = torch.bincount(target, minlength=num_classes).float()
+    n_pred = torch.bincount(pred, minlength=num_classes).float()
+    p, r = tp / n_pred, tp / n_label
+    return torch.nan_to_num(2 * p * r / (p + r))
+
+
+def install_stubs():
+    def mod(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+        return m
+
+    class _Any:
+        def __init__(self, *a, **k):
+            pass
+
+    tv = mod("torchvision")
+    tv.transforms = mod("torchvision.transforms", Compose=_Any, Resize=_Any, CenterCrop=_Any, ToTensor=_Any,
+                        Normalize=_Any, InterpolationMode=SimpleNamespace(BICUBIC=3))
+    mod("ftfy", fix_text=lambda s: s)
+    te = mod("torcheval")
+    te.metrics = mod("torcheval.metrics")
+    te.metrics.functional = mod("torcheval.metrics.functional", multiclass_f1_score=_f1_stub,
+                                multiclass_precision=None, multiclass_recall=None)
+
+    class _Registry:
+        def register(self):
+            return lambda cls: cls
+
+    class TrainerX:
+        pass
+
+    d = mod("dassl")
+    d.engine = mod("dassl.engine", TRAINER_REGISTRY=_Registry(), TrainerX=TrainerX)
+    d.metrics = mod("dassl.metrics", compute_accuracy=None)
+    d.utils = mod("dassl.utils", load_pretrained_weights=None, load_checkpoint=None)
+    d.optim = mod("dassl.optim", build_optimizer=None, build_lr_scheduler=None)
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    torch.nn.Module.cuda = lambda self, *a, **k: self
+
+
+def import_reference():
+    install_stubs()
+    sys.path.insert(0, REF)
+    import clip.model as ref_model                       # L1
+    from clip import clip as ref_clip                    # tokenizer
+    import trainers.mm_classifier_one_prompt as ref_l2   # L2
+    return ref_model, ref_clip, ref_l2
+
+
+def make_cfg(n_ctx, shots, tau, mode, outdir, train_n_ins=8):
+    return SimpleNamespace(
+        TRAINER=SimpleNamespace(COCOOP=SimpleNamespace(N_CTX=n_ctx, PREC="fp16")),
+        INPUT=SimpleNamespace(SIZE=(224, 224)),       # only compared with the constant 224 (:103-107)
+        DATALOADER=SimpleNamespace(TRAIN_X=SimpleNamespace(BATCH_SIZE=64, N_INS=train_n_ins), K_TRANSFORMS=1),
+        DATASET=SimpleNamespace(NUM_SHOTS=shots),
+        EVAL_TAU=tau, EVAL_MODE=mode, OUTPUT_DIR=outdir,
+        MODEL=SimpleNamespace(BACKBONE=SimpleNamespace(NAME="synthetic")))
+
+
+def build_ref_clip(ref_model, spec, seed, jitter, fp32=False):
+    sd = {k: torch.from_numpy(v) for k, v in synth.clip_state_dict(spec, seed, jitter).items()}
+    model = ref_model.build_model(dict(sd))               # convert_weights -> fp16 + load_state_dict
+    if fp32:
+        model = model.float()
+    return model.eval()
+
+
+CLASSNAMES = ["accordion", "bass guitar", "airplane", "sea_horse", "stop sign", "yin yang"]
+
+
+# ----------------------------------------------------------------------------- L1 vectors
+@torch.no_grad()
+def gen_l1(ref_model, spec, seed, n_img, with_taps, out):
+    img = torch.from_numpy(synth.images(n_img, spec.image_resolution, seed=1234))
+    ids = torch.from_numpy(synth.class_token_ids(6, seed=4321))
+    for tag, fp32 in (("fp16", False), ("fp32", True)):
+        m = build_ref_clip(ref_model, spec, seed, True, fp32)
+        x = img.to(m.dtype)
+        if with_taps:
+            v = m.visual
+            t = v.conv1(x)
+            t = t.reshape(t.shape[0], t.shape[1], -1).permute(0, 2, 1)
+            t = torch.cat([v.class_embedding.to(t.dtype) + torch.zeros(t.shape[0], 1, t.shape[-1], dtype=t.dtype), t], 1)
+            t = t + v.positional_embedding.to(t.dtype)
+            out[f"l1_{tag}_tokens"] = t.float().numpy()
+            t = v.ln_pre(t)
+            out[f"l1_{tag}_ln_pre"] = t.float().numpy()
+            t = t.permute(1, 0, 2)
+            for i, blk in enumerate(v.transformer.resblocks):
+                t = blk(t)
+                out[f"l1_{tag}_block{i}"] = t.permute(1, 0, 2).float().numpy()
+        out[f"l1_{tag}_image_features"] = m.encode_image(x).float().numpy()
+        out[f"l1_{tag}_text_features"] = m.encode_text(ids).float().numpy()
+        # zsclip-style raw logits (trainers/zsclip.py:55-60); that file itself is unimportable
+        f = m.encode_image(x)
+        f = f / f.norm(dim=-1, keepdim=True)
+        tf = m.encode_text(ids)
+        tf = tf / tf.norm(dim=-1, keepdim=True)
+        out[f"l1_{tag}_zs_logits"] = (m.logit_scale.exp() * f @ tf.t()).float().numpy()
+
+
+# ----------------------------------------------------------------------------- L2 vectors
+@torch.no_grad()
+def gen_l2(ref_model, ref_clip, ref_l2, spec, seed, n_ctx, shots, tau, classes_per_batch, n_query, out, tag):
+    C = len(CLASSNAMES)
+    with tempfile.TemporaryDirectory() as outdir:
+        cfg = make_cfg(n_ctx, shots, tau, "fusion", outdir)
+        clip_model = build_ref_clip(ref_model, spec, seed, True)
+        torch.manual_seed(0)
+        model = ref_l2.CustomCLIP(cfg, CLASSNAMES, clip_model).eval()
+        pl_sd = {k: torch.from_numpy(v) for k, v in synth.prompt_learner_state_dict(spec, n_ctx, seed, True).items()}
+        missing = model.prompt_learner.load_state_dict(pl_sd, strict=True)
+        model.device = torch.device("cpu")
+
+        tok = model.tokenized_prompts
+        out[f"{tag}_tokenized_prompts"] = tok.numpy()
+        out[f"{tag}_prompt_tokens"] = model.prompt_learner.prompt_tokens.float().numpy()
+        out[f"{tag}_zero_shot_classifier"] = model.zero_shot_classifier.float().numpy()
+
+        # eval-set loader contract: S consecutive rows per class, classes shuffled
+        order = [3, 0, 5, 1, 2, 4][:C]
+        labels = np.repeat(np.array(order, dtype=np.int64), shots)
+        img = synth.images(C * shots, spec.image_resolution, seed=1234, class_ids=labels, class_strength=0.6)
+        out[f"{tag}_eval_labels"] = labels
+        step = classes_per_batch * shots
+        loader = [{"img": torch.from_numpy(img[s:s + step]), "label": torch.from_numpy(labels[s:s + step])}
+                  for s in range(0, C * shots, step)]
+
+        # PromptLearner.forward / TextEncoder.forward vectors on the first batch
+        b0 = loader[0]
+        ex_label = b0["label"].reshape(-1, shots)[:, 0]
+        f = model.image_encoder(b0["img"].half())
+        f = (f / f.norm(dim=-1, keepdim=True)).reshape(len(ex_label), shots, -1)
+        eos = tok[ex_label].argmax(dim=-1)
+        mm_p, mm_l, v_p, v_l, tokens = model.prompt_learner(f, ex_label, eos)
+        out[f"{tag}_pl_feats"] = f.float().numpy()
+        out[f"{tag}_pl_label"] = ex_label.numpy()
+        out[f"{tag}_pl_eos"] = eos.numpy()
+        out[f"{tag}_pl_tokens"] = tokens.float().numpy()
+        out[f"{tag}_pl_mm_prompts"] = mm_p[0].float().numpy()
+        out[f"{tag}_pl_v_prompts"] = v_p[0].float().numpy()
+        out[f"{tag}_pl_mm_lens"] = mm_l.numpy()
+        out[f"{tag}_pl_v_lens"] = v_l.numpy()
+        out[f"{tag}_te_mm"] = model.text_encoder(mm_p[0], mm_l).float().numpy()
+        out[f"{tag}_te_v"] = model.text_encoder(v_p[0], v_l).float().numpy()
+
+        # full generation + the four inference modes
+        qlab = np.arange(n_query, dtype=np.int64) % C
+        q = torch.from_numpy(synth.images(n_query, spec.image_resolution, seed=777, class_ids=qlab, class_strength=0.6))
+        out[f"{tag}_query_labels"] = qlab
+        for mode in ("fusion", "text", "vision", "multimodal"):
+            cfg.EVAL_MODE = mode
+            out[f"{tag}_logits_{mode}"] = model(q, eval_set_loader=loader).float().numpy()
+        qf = model.image_encoder(q.half())
+        out[f"{tag}_query_features"] = (qf / qf.norm(dim=-1, keepdim=True)).float().numpy()
+        saved = torch.load(os.path.join(outdir, "mm_classifiers.pt"))
+        for k, v in saved.items():
+            assert v.dtype == torch.float32
+            out[f"{tag}_saved_{k}"] = v.numpy()
+        vt = torch.load(os.path.join(outdir, "visual_tokens.pt"))["visual_tokens"]
+        assert vt.dtype == torch.float16
+        out[f"{tag}_saved_visual_tokens"] = vt.float().numpy()
+        out[f"{tag}_eval_feat4cls"] = model.eval_feat4cls.float().numpy()
+        out[f"{tag}_state_dict_keys"] = np.array(sorted(model.prompt_learner.state_dict().keys()))
+
+
+def gen_tokenizer(ref_clip, out):
+    names = ["a .", "a accordion.", "a bass guitar.", "a sea horse.", "a photo of a yin yang."]
+    out["tok_texts"] = np.array(names)
+    out["tok_ids"] = torch.cat([ref_clip.tokenize(t) for t in names]).numpy()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default="all")
+    args = ap.parse_args()
+    torch.set_num_threads(os.cpu_count())
+    ref_model, ref_clip, ref_l2 = import_reference()
+
+    if args.only in ("all", "tok"):
+        out = {}
+        gen_tokenizer(ref_clip, out)
+        np.savez_compressed(os.path.join(HERE, "tokenizer.npz"), **out)
+        print("tokenizer.npz", {k: v.shape for k, v in out.items()})
+
+    for name, n_img, taps, shots, cpb, nq in (("tiny", 4, True, 4, 2, 5), ("small", 3, True, 4, 4, 5),
+                                               ("ViT-B/16", 8, False, 4, 2, 5)):
+        key = {"tiny": "tiny", "small": "small", "ViT-B/16": "vitb16"}[name]
+        if args.only not in ("all", key):
+            continue
+        spec = synth.SPECS[name]
+        out = {"meta_spec": np.array(name), "meta_seed": np.array(11), "meta_shots": np.array(shots),
+               "meta_classes_per_batch": np.array(cpb), "meta_tau": np.array(10.0)}
+        gen_l1(ref_model, spec, 11, n_img, taps, out)
+        gen_l2(ref_model, ref_clip, ref_l2, spec, 11, 2, shots, 10.0, cpb, nq, out, "l2")
+        if key != "vitb16":
+            gen_l2(ref_model, ref_clip, ref_l2, spec, 11, 1, shots, 10.0, cpb, nq, out, "l2n1")
+        # fp16-valued tensors are stored as float16 (lossless, checked); everything else as produced
+        store = {}
+        for k, v in out.items():
+            if v.dtype == np.float32 and v.size > 1024:
+                with np.errstate(over="ignore"):
+                    h = v.astype(np.float16)
+                if np.array_equal(h.astype(np.float32), v):
+                    v = h
+            store[k] = v
+        path = os.path.join(HERE, f"{key}.npz")
+        np.savez_compressed(path, **store)
+        print(path, os.path.getsize(path) // 1024, "KiB")
+
+
+if __name__ == "__main__":
+    main()
