@@ -1,0 +1,163 @@
+/* libovmr_hip.so -- C ABI of the MI355X (gfx950) implementation of OVMR's hot path.
+ *
+ * The reference (Zehong-Ma/OVMR) has no FFI: its boundary for this path is a set of Python
+ * nn.Module methods.  Each entry point below replaces the arithmetic of one of them; the Python
+ * layer in ovmr_amd/modules.py keeps the reference's module API on top (INTEGRATION.md shows the
+ * ctypes stub a maintainer of the reference would add).  Paths are relative to the reference root.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller unless stated otherwise (PyTorch
+ *     allocates, passes tensor.data_ptr()); the library owns only its weight arena and workspace;
+ *   - every compute call is asynchronous on the caller's hipStream_t, performs no allocation and
+ *     no host synchronisation (graph-capturable), and may be called with any batch size up to
+ *     what ovmr_reserve() sized (larger batches are processed in chunks);
+ *   - return value: 0 = ok, otherwise an OVMR_E_* code or a positive hipError_t;
+ *     ovmr_last_error(h) returns a message for the last failure on that handle;
+ *   - one handle per (device, model, stream user): thread-compatible, not thread-safe;
+ *   - fp16 = IEEE binary16 ("half"), the reference's only working OVMR precision
+ *     (configs/trainers/MM_CLS_OP/vit_b16_c4_ep50_imagenet21k_pretrain.yaml:42).
+ */
+#ifndef OVMR_HIP_H
+#define OVMR_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ovmr_handle ovmr_handle;
+typedef void* ovmr_stream;              /* hipStream_t */
+
+enum { OVMR_F16 = 0, OVMR_F32 = 1, OVMR_I64 = 2, OVMR_I32 = 3 };
+enum { OVMR_MODE_FUSION = 0, OVMR_MODE_TEXT = 1, OVMR_MODE_VISION = 2, OVMR_MODE_MULTIMODAL = 3 };
+enum {
+    OVMR_OK = 0,
+    OVMR_E_ARG = -1,         /* bad argument / shape            */
+    OVMR_E_SHAPE = -2,       /* unsupported dimension           */
+    OVMR_E_STATE = -4,       /* weights missing / not finalized */
+    OVMR_E_NOMEM = -5,
+    OVMR_E_NAME = -6         /* unknown weight name             */
+};
+
+/* Architecture, exactly the constructor arguments of CLIP (clip/model.py:717-731) that
+ * build_model() infers from a state dict (clip/model.py:899-928), plus the prompt learner's
+ * n_ctx (trainers/mm_classifier_one_prompt.py:99) and its fixed 4 aggregator layers (:140). */
+typedef struct {
+    int embed_dim;            /* 512 (ViT-B), 768 (ViT-L)        */
+    int image_resolution;     /* 224 / 336                       */
+    int vision_layers;
+    int vision_width;         /* heads = width / 64              */
+    int vision_patch_size;
+    int context_length;       /* 77                              */
+    int vocab_size;           /* 49408                           */
+    int transformer_width;    /* heads = width / 64              */
+    int transformer_layers;
+    int n_ctx;                /* visual tokens per class         */
+    int agg_layers;           /* 4                               */
+} ovmr_model_desc;
+
+int  ovmr_create(const ovmr_model_desc* desc, ovmr_handle** out);
+void ovmr_destroy(ovmr_handle* h);
+const char* ovmr_last_error(const ovmr_handle* h);
+const char* ovmr_version(void);
+
+/* Kernel-variant switch used by tests/bench to A/B implementations: key in {"gemm","attn"}. */
+int ovmr_set_option(ovmr_handle* h, const char* key, int value);
+
+/* Weight ingestion -- replaces build_model()/convert_weights()/load_state_dict
+ * (clip/model.py:852-873,899-936) and PromptLearner.load_state_dict
+ * (trainers/mm_classifier_one_prompt.py:461-493).  `name` is the reference state-dict key
+ * ("visual.conv1.weight", "transformer.resblocks.3.attn.in_proj_weight", "text_projection",
+ * "logit_scale", ... and, prefixed "prompt_learner.", "cls_token" /
+ * "aggregator.resblocks.N.*").  Data is copied (and converted to the reference's dtype policy:
+ * Linear/Conv/MHA/proj fp16, LayerNorm + embeddings fp32, aggregator fp32) on `stream`. */
+int ovmr_set_weight(ovmr_handle* h, const char* name, const void* data, int dtype,
+                    int ndim, const int64_t* shape, ovmr_stream stream);
+/* Validates that every tensor is present, builds derived layouts (transposed projections,
+ * fp16 positional tables) and sizes the workspace for `max_images` images / `max_prompts`
+ * text sequences / `max_classes` classes per call.  Synchronises `stream` once. */
+int ovmr_finalize(ovmr_handle* h, int max_images, int max_prompts, int max_classes, ovmr_stream stream);
+
+/* VisionTransformer.forward (clip/model.py:411-428) [+ x / x.norm() when normalize != 0,
+ * trainers/mm_classifier_one_prompt.py:244,307].  image: [B,3,R,R] fp16 or fp32 (cast to fp16 on
+ * device like image.type(self.dtype), :243/:306); out: [B, embed_dim] fp16. */
+int ovmr_encode_image(ovmr_handle* h, const void* image, int image_dtype, int B,
+                      void* out_f16, int normalize, ovmr_stream stream);
+
+/* TextEncoder.forward (trainers/mm_classifier_one_prompt.py:80-91).  prompts: [N, context_length,
+ * transformer_width] fp16 (already embedded); index: [N] int32 row that is projected (EOS for mm
+ * prompts, 1+n_ctx for vision prompts, :163-165); seq_len: number of leading positions that must
+ * be computed (max(index)+1 <= seq_len <= context_length; the mask is causal so truncation is
+ * exact); normalize: 0 = raw, 1 = x/x.norm(), 2 = the double normalisation of get_mm_v_feats
+ * (:204,210).  out: [N, embed_dim] fp16. */
+int ovmr_encode_text_embedded(ovmr_handle* h, const void* prompts_f16, const int32_t* index, int N,
+                              int seq_len, void* out_f16, int normalize, ovmr_stream stream);
+
+/* CLIP.encode_text (clip/model.py:820-833): ids [N, context_length] int64; the projected row is
+ * ids.argmax(-1).  normalize as above (the zero-shot text classifier uses 1, :118-126). */
+int ovmr_encode_text_ids(ovmr_handle* h, const int64_t* ids, int N, int seq_len,
+                         void* out_f16, int normalize, ovmr_stream stream);
+
+/* token_embedding(ids).type(fp16) (trainers/mm_classifier_one_prompt.py:129-130): ids [N, L] int64
+ * -> out [N, L, transformer_width] fp16. */
+int ovmr_embed_tokens(ovmr_handle* h, const int64_t* ids, int N, int L, void* out_f16, ovmr_stream stream);
+
+/* PromptLearner.forward, visual-token generator part (trainers/mm_classifier_one_prompt.py:167-169):
+ * feats [Cb, S, embed_dim] fp16 -> tokens [Cb, n_ctx, embed_dim] fp32 (aggregator in fp32). */
+int ovmr_generate_tokens(ovmr_handle* h, const void* feats_f16, int Cb, int S,
+                         float* tokens_f32, ovmr_stream stream);
+
+/* PromptLearner.update_prompts (:156-157): out[c] = cat(base[row(c)][:2], half(tokens[c]),
+ * base[row(c)][2:-n_ctx]); row(c) = labels[c] (int64) or 0 when labels == NULL (the "a ." template
+ * broadcast, :173).  base: [*, context_length, width] fp16; out: [Cb, context_length, width] fp16. */
+int ovmr_assemble_prompts(ovmr_handle* h, const void* base_f16, const int64_t* labels,
+                          const float* tokens_f32, int Cb, void* out_f16, ovmr_stream stream);
+
+/* Cross-validation counts (trainers/mm_classifier_one_prompt.py:261-270): for rows r of
+ * feats [R, embed_dim] fp16 with int32 labels [R], logits = logit_scale * feats @ clf^T in fp16
+ * (clf [C, embed_dim] fp16), pred = argmax (first index on ties); accumulates
+ * n_pred[pred] += 1 and tp[label] += (pred == label) into int32 [C] arrays (caller zeroes). */
+int ovmr_xval_counts(ovmr_handle* h, const void* feats_f16, const int32_t* labels, int R,
+                     const void* clf_f16, int C, int32_t* tp, int32_t* n_pred, ovmr_stream stream);
+
+/* F1 preference (:268-274): counts int32 [3][2][C] = {mm, vision, text} x {tp, n_pred},
+ * n_label int32 [C]; out [C,3] fp32 = softmax(tau * f1) with f1 = 2pr/(p+r), NaN -> 0
+ * (torcheval==0.0.7 multiclass_f1_score(average=None)). */
+int ovmr_fusion_weights(ovmr_handle* h, const int32_t* counts, const int32_t* n_label, int C,
+                        float tau, float* out_f32, ovmr_stream stream);
+
+/* CustomCLIP.forward eval branch (:348-363).  feats [B, embed_dim] fp16 (L2-normalised);
+ * mm / v / t classifiers [C, embed_dim] fp16 (unused ones may be NULL for single modes);
+ * w [C,3] fp32 (fusion only); out [B,C] fp32 probabilities. */
+int ovmr_fused_logits(ovmr_handle* h, const void* feats_f16, int B, const void* mm_f16,
+                      const void* v_f16, const void* t_f16, const float* w_f32, int C, int mode,
+                      float* out_f32, ovmr_stream stream);
+
+/* ZeroshotCLIP.model_inference (trainers/zsclip.py:55-60): out [B,C] fp16 =
+ * exp(logit_scale) * feats @ text_feats^T (raw logits). */
+int ovmr_zeroshot_logits(ovmr_handle* h, const void* feats_f16, int B, const void* text_f16, int C,
+                         void* out_f16, ovmr_stream stream);
+
+/* exp(logit_scale) as held by the handle (set through ovmr_set_weight("logit_scale")). */
+float ovmr_logit_scale(const ovmr_handle* h);
+
+/* Closed-form FLOP counts used for every roofline fraction. */
+double ovmr_flops_per_image(const ovmr_handle* h);
+double ovmr_flops_per_prompt(const ovmr_handle* h, int seq_len);
+
+/* Unit-test hooks: launch ONE kernel (no handle).  f32 selects the fp32 (aggregator) kernels;
+ * `variant` selects the kernel implementation as ovmr_set_option does; `epi` is the epilogue id of
+ * ovmr_amd/csrc/common.h.  A [M,K], W [N,K], C [M,ldc]; qkv [B*L, 3*H*64] -> out [B*L, H*64]. */
+int ovmr_debug_gemm(int f32, int variant, const void* A, const void* W, const void* bias, const void* res,
+                    const void* pos, void* C, int M, int N, int K, int ldc, int epi, float scale,
+                    int rows_in, int rows_out, ovmr_stream stream);
+int ovmr_debug_layernorm(int f32, const void* x, void* y, const float* g, const float* b, int rows, int D,
+                         long in_stride, ovmr_stream stream);
+int ovmr_debug_attention(int f32, int variant, const void* qkv, void* out, int B, int L, int H, int causal,
+                         ovmr_stream stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OVMR_HIP_H */

@@ -1,0 +1,57 @@
+"""Build libovmr_hip.so for gfx950 with hipcc (cross-compiles without a GPU).
+
+    python -m ovmr_amd.build            # incremental, parallel per translation unit
+The library lands in ovmr_amd/lib/ (git-ignored, but it travels to the GPU box with gpurun).
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(HERE, "lib", "obj")
+LIB = os.path.join(HERE, "lib", "libovmr_hip.so")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-mcode-object-version=5",
+         "-Wno-unused-result", "-ffp-contract=off"]
+
+
+def _stale(out, deps):
+    if not os.path.exists(out):
+        return True
+    t = os.path.getmtime(out)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(verbose: bool = True, force: bool = False) -> str:
+    os.makedirs(OBJ, exist_ok=True)
+    srcs = sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
+    hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    hdrs.append(os.path.join(os.path.dirname(HERE), "include", "ovmr_hip.h"))
+    jobs = []
+    for f in srcs:
+        src, obj = os.path.join(CSRC, f), os.path.join(OBJ, f[:-4] + ".o")
+        if force or _stale(obj, [src] + hdrs):
+            jobs.append([HIPCC, *FLAGS, "-c", src, "-o", obj])
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc failed: {' '.join(cmd)}\n{r.stdout}\n{r.stderr}")
+        return r
+
+    with ThreadPoolExecutor(max_workers=min(4, max(1, len(jobs)))) as ex:
+        list(ex.map(run, jobs))
+    objs = [os.path.join(OBJ, f[:-4] + ".o") for f in srcs]
+    if force or jobs or _stale(LIB, objs):
+        run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB])
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv))

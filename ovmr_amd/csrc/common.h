@@ -1,0 +1,90 @@
+// Shared device/host helpers for the OVMR gfx950 kernels (wave64, MFMA 16x16x32 f16).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef _Float16 half_t;
+typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
+typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
+typedef float float4_t __attribute__((ext_vector_type(4)));
+typedef float float2_t __attribute__((ext_vector_type(2)));
+
+#define OVMR_WAVE 64
+
+// GEMM epilogues (C = epi(A * W^T)), rounding points follow the reference's fp16 CPU path:
+// every nn.Linear output is rounded to fp16 before the next elementwise op.
+enum {
+    EPI_NONE = 0,        // C = h(acc)
+    EPI_BIAS = 1,        // C = h(acc + bias)                        nn.Linear            (clip/model.py:171,173-177)
+    EPI_BIAS_QGELU = 2,  // u = h(acc+bias); C = u * sigmoid(1.702u) c_fc + QuickGELU     (clip/model.py:162-164)
+    EPI_BIAS_RES = 3,    // C = h(h(acc+bias) + res)                 x + attn / x + mlp   (clip/model.py:192-193)
+    EPI_PATCH = 4,       // C[b*Lout+1+p] = h(h(acc) + pos[1+p])     conv1 + pos add      (clip/model.py:412-416)
+    EPI_SCALE = 5,       // C = h(h(acc) * scale)                    logit_scale * einsum (trainers/mm_classifier_one_prompt.py:263)
+};
+
+struct GemmArgs {
+    const void* A; int lda;     // [M,K] row-major
+    const void* W; int ldw;     // [N,K] row-major (nn.Linear weight layout)
+    void* C; int ldc;           // [M,N] row-major
+    const void* bias;           // [N] or nullptr
+    const void* res; int ldres; // [M,N] residual (may alias C) or nullptr
+    const void* pos;            // EPI_PATCH: fp16 [Lout, N]
+    int M, N, K;
+    int epi;
+    int rows_in, rows_out;      // EPI_PATCH: patches per image (G*G) and tokens per image (G*G+1)
+    float scale;                // EPI_SCALE
+};
+
+__device__ __forceinline__ float quick_gelu_h(float u) {
+    // fp16 rounding points of `x * torch.sigmoid(1.702 * x)` on an fp16 tensor
+    half_t t = (half_t)(1.702f * u);
+    half_t s = (half_t)(1.0f / (1.0f + __expf(-(float)t)));
+    return (float)(half_t)(u * (float)s);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+#define HIP_CHECK_RET(expr)                                   \
+    do {                                                      \
+        hipError_t _e = (expr);                               \
+        if (_e != hipSuccess) return (int)_e;                 \
+    } while (0)
+
+// ---- launchers (one per .hip translation unit) -------------------------------------------
+int launch_gemm_f16(const GemmArgs& a, int variant, hipStream_t s);
+int launch_gemm_f32(const GemmArgs& a, hipStream_t s);
+int launch_layernorm(const void* x, void* y, const float* g, const float* b, int rows, int D,
+                     long in_row_stride, int is_f32, hipStream_t s);
+int launch_attention_f16(const half_t* qkv, half_t* out, int B, int L, int H, int causal, int variant, hipStream_t s);
+int launch_attention_f32(const float* qkv, float* out, int B, int L, int H, hipStream_t s);
+int launch_im2col(const void* img, int img_is_f32, half_t* out, int B, int R, int P, int Kpad, hipStream_t s);
+int launch_fill_cls(half_t* x, const half_t* cls_pos, int B, int L, int W, hipStream_t s);
+int launch_l2norm_f16(half_t* x, int rows, int D, hipStream_t s);
+int launch_cast(const void* src, int src_f32, void* dst, int dst_f32, long n, hipStream_t s);
+int launch_transpose_to_f16(const void* src, int src_f32, half_t* dst, int rows, int cols, hipStream_t s);
+int launch_pad_rows_f16(const half_t* src, half_t* dst, int rows, int cols, int cols_pad, hipStream_t s);
+int launch_add_f16(const half_t* a, const half_t* b, half_t* out, long n, hipStream_t s);
+int launch_text_embed_ids(const int64_t* ids, int ids_stride, const float* tok_emb, const half_t* pos16,
+                          half_t* x, int* index, int N, int Lctx, int Lseq, int D, hipStream_t s);
+int launch_embed_gather(const int64_t* ids, const float* tok_emb, half_t* out, long rows, int D, hipStream_t s);
+int launch_text_add_pos(const half_t* prompts, int Lctx, const half_t* pos16, half_t* x, int N, int Lseq, int D, hipStream_t s);
+int launch_gather_rows_f16(const half_t* x, const int* index, half_t* out, int N, int Lseq, int D, hipStream_t s);
+int launch_agg_input(const float* cls_token, const half_t* feats, float* x, int Cb, int S, int n_ctx, int D, hipStream_t s);
+int launch_agg_output(const float* x, float* tokens, int Cb, int La, int n_ctx, int D, hipStream_t s);
+int launch_assemble_prompts(const half_t* base, const int64_t* labels, const float* tokens, half_t* out,
+                            int Cb, int Lctx, int n_ctx, int D, hipStream_t s);
+int launch_argmax_counts(const half_t* logits, int ld, const int* labels, int R, int C, int* tp, int* n_pred, hipStream_t s);
+int launch_fusion_weights(const int* counts, const int* n_label, int C, float tau, float* out, hipStream_t s);
+int launch_scale_f16(const half_t* x, half_t* y, float scale, long n, hipStream_t s);
+int launch_fused_softmax(const half_t* l0, const half_t* l1, const half_t* l2, const float* w, int n_mod,
+                         float* out, int B, int C, hipStream_t s);

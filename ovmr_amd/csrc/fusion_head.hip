@@ -1,0 +1,119 @@
+// OVMR classifier-fusion head (trainers/mm_classifier_one_prompt.py:261-274, 348-363).
+//   * xval_argmax_counts: K19 -- per exemplar row argmax over the class logits, then the per-class
+//     true-positive / prediction histograms that torcheval's multiclass_f1_score(average=None)
+//     builds (torcheval==0.0.7, requirements.txt:16).  Ties resolve to the lowest class index
+//     (torch.argmax on CPU).
+//   * fusion_weights: K20 -- f1 = 2pr/(p+r), NaN -> 0, softmax(tau * [f1_mm, f1_v, f1_t]).
+//   * fused_softmax: K21/K22 -- per query row, softmax over classes of each modality's fp16
+//     logits in fp32, then sum_n p[b,c,n] * w[c,n] (column order mm, vision, text).
+// All three are HBM/L2-bound row kernels; the logits themselves come from the MFMA GEMM.
+#include "common.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void xval_argmax_counts(const half_t* __restrict__ logits, int ld,
+                                                          const int* __restrict__ labels, int rows, int C,
+                                                          int* __restrict__ tp, int* __restrict__ n_pred) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const half_t* lr = logits + (long)row * ld;
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int c = lane; c < C; c += 64) {
+        const float v = (float)lr[c];
+        if (v > best || bi == 0x7fffffff) { best = v; bi = c; }   // strict >: first index wins inside a lane
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(best, o, 64);
+        const int oi = __shfl_xor(bi, o, 64);
+        if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+    }
+    if (lane == 0 && bi < C) {
+        atomicAdd(n_pred + bi, 1);
+        if (bi == labels[row]) atomicAdd(tp + bi, 1);
+    }
+}
+
+// counts: int32 [3][2][C] = {mm, vision, text} x {tp, n_pred}; n_label: int32 [C]
+__global__ void fusion_weights_kernel(const int* __restrict__ counts, const int* __restrict__ n_label, int C,
+                                      float tau, float* __restrict__ out) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float f1[3];
+#pragma unroll
+    for (int m = 0; m < 3; ++m) {
+        const float tp = (float)counts[(m * 2 + 0) * C + c];
+        const float np = (float)counts[(m * 2 + 1) * C + c];
+        const float precision = tp / np;                 // 0/0 -> NaN like torch
+        const float recall = tp / (float)n_label[c];
+        float f = 2.f * precision * recall / (precision + recall);
+        if (f != f) f = 0.f;                             // torch.nan_to_num
+        f1[m] = tau * f;
+    }
+    const float mx = fmaxf(f1[0], fmaxf(f1[1], f1[2]));
+    const float e0 = __expf(f1[0] - mx), e1 = __expf(f1[1] - mx), e2 = __expf(f1[2] - mx);
+    const float inv = 1.f / (e0 + e1 + e2);
+    out[c * 3 + 0] = e0 * inv;
+    out[c * 3 + 1] = e1 * inv;
+    out[c * 3 + 2] = e2 * inv;
+}
+
+__device__ __forceinline__ float block_reduce(float v, bool is_max, float* red) {
+    v = is_max ? wave_max(v) : wave_sum(v);
+    const int wave = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[wave] = v;
+    __syncthreads();
+    float r = red[0];
+    for (int i = 1; i < (int)(blockDim.x >> 6); ++i) r = is_max ? fmaxf(r, red[i]) : r + red[i];
+    return r;
+}
+
+// out[b][c] = sum_m softmax_c(float(l_m[b]))[c] * w[c][m]   (w == nullptr: single modality, weight 1)
+__global__ __launch_bounds__(256) void fused_softmax_kernel(const half_t* __restrict__ l0, const half_t* __restrict__ l1,
+                                                            const half_t* __restrict__ l2, const float* __restrict__ w,
+                                                            int n_mod, float* __restrict__ out, int C) {
+    __shared__ float red[4];
+    const int b = blockIdx.x;
+    const half_t* ls[3] = {l0 + (long)b * C, l1 ? l1 + (long)b * C : nullptr, l2 ? l2 + (long)b * C : nullptr};
+    float mx[3], inv[3];
+    for (int m = 0; m < n_mod; ++m) {
+        float v = -INFINITY;
+        for (int c = threadIdx.x; c < C; c += blockDim.x) v = fmaxf(v, (float)ls[m][c]);
+        mx[m] = block_reduce(v, true, red);
+        float sum = 0.f;
+        for (int c = threadIdx.x; c < C; c += blockDim.x) sum += __expf((float)ls[m][c] - mx[m]);
+        inv[m] = 1.f / block_reduce(sum, false, red);
+    }
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        float acc = 0.f;
+        for (int m = 0; m < n_mod; ++m) {
+            const float p = __expf((float)ls[m][c] - mx[m]) * inv[m];
+            acc += w ? p * w[c * 3 + m] : p;
+        }
+        out[(long)b * C + c] = acc;
+    }
+}
+
+}  // namespace
+
+int launch_argmax_counts(const half_t* logits, int ld, const int* labels, int R, int C, int* tp, int* n_pred, hipStream_t s) {
+    if (R <= 0) return 0;
+    hipLaunchKernelGGL(xval_argmax_counts, dim3((R + 3) / 4), dim3(256), 0, s, logits, ld, labels, R, C, tp, n_pred);
+    return (int)hipGetLastError();
+}
+
+int launch_fusion_weights(const int* counts, const int* n_label, int C, float tau, float* out, hipStream_t s) {
+    if (C <= 0) return 0;
+    hipLaunchKernelGGL(fusion_weights_kernel, dim3((C + 255) / 256), dim3(256), 0, s, counts, n_label, C, tau, out);
+    return (int)hipGetLastError();
+}
+
+int launch_fused_softmax(const half_t* l0, const half_t* l1, const half_t* l2, const float* w, int n_mod,
+                         float* out, int B, int C, hipStream_t s) {
+    if (B <= 0) return 0;
+    hipLaunchKernelGGL(fused_softmax_kernel, dim3(B), dim3(256), 0, s, l0, l1, l2, w, n_mod, out, C);
+    return (int)hipGetLastError();
+}

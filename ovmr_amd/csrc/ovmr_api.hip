@@ -1,0 +1,596 @@
+// C ABI of libovmr_hip.so (see include/ovmr_hip.h): weight arena, workspace and the launch
+// sequences of the OVMR hot path.  No call in the compute entry points allocates, copies to the
+// host or synchronises, so every one of them can be captured into a hipGraph by the caller.
+#include "../../include/ovmr_hip.h"
+#include "common.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+namespace {
+
+struct Buf {
+    void* p = nullptr;
+    size_t elems = 0;
+    int f32 = 0;
+    std::vector<int64_t> shape;
+};
+
+struct Block {   // one residual attention block; element type depends on the tower
+    void *in_w, *in_b, *out_w, *out_b, *fc_w, *fc_b, *pj_w, *pj_b;
+    float *ln1_g, *ln1_b, *ln2_g, *ln2_b;
+};
+
+}  // namespace
+
+struct ovmr_handle {
+    ovmr_model_desc d;
+    std::map<std::string, Buf> w;
+    std::vector<void*> owned;
+    std::string err;
+    bool finalized = false;
+    int gemm_variant = 0, attn_variant = 0;
+    float logit_scale_exp = 100.f;
+    bool have_logit_scale = false;
+
+    std::vector<Block> vis, txt, agg;
+    half_t *conv_w = nullptr, *pos16_vis = nullptr, *cls_pos16 = nullptr, *proj_t = nullptr;
+    half_t *pos16_txt = nullptr, *textproj_t = nullptr;
+    float *ln_pre_g = nullptr, *ln_pre_b = nullptr, *ln_post_g = nullptr, *ln_post_b = nullptr;
+    float *ln_final_g = nullptr, *ln_final_b = nullptr, *tok_emb = nullptr, *cls_token = nullptr;
+    int Kpad = 0, G = 0, L = 0;
+
+    char* ws = nullptr;
+    size_t ws_bytes = 0;
+    int max_images = 0, max_prompts = 0, max_classes = 0;
+    long agg_rows_cap = 0, logit_elems_cap = 0;
+};
+
+namespace {
+
+int fail(ovmr_handle* h, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (h) h->err = buf;
+    return code;
+}
+
+#define CK(expr)                                                                         \
+    do {                                                                                 \
+        int _rc = (expr);                                                                \
+        if (_rc != 0) return fail(h, _rc, "%s failed with %d (%s:%d)", #expr, _rc, __FILE__, __LINE__); \
+    } while (0)
+
+bool ends_with(const std::string& s, const char* suf) {
+    const size_t n = strlen(suf);
+    return s.size() >= n && s.compare(s.size() - n, n, suf) == 0;
+}
+
+// dtype policy of convert_weights() (clip/model.py:852-873); the aggregator is never halved.
+bool stored_as_f32(const std::string& name) {
+    if (name.rfind("prompt_learner.", 0) == 0) return true;
+    if (name.find(".ln_") != std::string::npos || name.rfind("ln_final", 0) == 0) return true;
+    if (name == "visual.class_embedding" || name == "visual.positional_embedding" ||
+        name == "positional_embedding" || name == "token_embedding.weight" || name == "logit_scale")
+        return true;
+    if (name.rfind("visual.ln_", 0) == 0) return true;
+    return false;   // conv1, proj, text_projection, attn.*, mlp.*
+}
+
+void* dev_alloc(ovmr_handle* h, size_t bytes) {
+    void* p = nullptr;
+    if (hipMalloc(&p, bytes ? bytes : 16) != hipSuccess) return nullptr;
+    h->owned.push_back(p);
+    return p;
+}
+
+const Buf* find(ovmr_handle* h, const std::string& name, size_t elems) {
+    auto it = h->w.find(name);
+    if (it == h->w.end()) { fail(h, OVMR_E_STATE, "weight '%s' was never set", name.c_str()); return nullptr; }
+    if (it->second.elems != elems) {
+        fail(h, OVMR_E_SHAPE, "weight '%s' has %zu elements, expected %zu", name.c_str(), it->second.elems, elems);
+        return nullptr;
+    }
+    return &it->second;
+}
+
+int bind_blocks(ovmr_handle* h, const std::string& prefix, int layers, int W, std::vector<Block>& out) {
+    out.resize(layers);
+    const size_t w = (size_t)W;
+    for (int i = 0; i < layers; ++i) {
+        const std::string p = prefix + std::to_string(i) + ".";
+        struct { const char* n; size_t e; void** dst; } items[] = {
+            {"attn.in_proj_weight", 3 * w * w, &out[i].in_w}, {"attn.in_proj_bias", 3 * w, &out[i].in_b},
+            {"attn.out_proj.weight", w * w, &out[i].out_w},   {"attn.out_proj.bias", w, &out[i].out_b},
+            {"mlp.c_fc.weight", 4 * w * w, &out[i].fc_w},     {"mlp.c_fc.bias", 4 * w, &out[i].fc_b},
+            {"mlp.c_proj.weight", 4 * w * w, &out[i].pj_w},   {"mlp.c_proj.bias", w, &out[i].pj_b},
+            {"ln_1.weight", w, (void**)&out[i].ln1_g},        {"ln_1.bias", w, (void**)&out[i].ln1_b},
+            {"ln_2.weight", w, (void**)&out[i].ln2_g},        {"ln_2.bias", w, (void**)&out[i].ln2_b}};
+        for (auto& it : items) {
+            const Buf* b = find(h, p + it.n, it.e);
+            if (!b) return OVMR_E_STATE;
+            *it.dst = b->p;
+        }
+    }
+    return 0;
+}
+
+GemmArgs gemm(const void* A, int lda, const void* W, int ldw, void* C, int ldc, int M, int N, int K, int epi,
+              const void* bias = nullptr, const void* res = nullptr, int ldres = 0) {
+    GemmArgs a;
+    memset(&a, 0, sizeof a);
+    a.A = A; a.lda = lda; a.W = W; a.ldw = ldw; a.C = C; a.ldc = ldc;
+    a.M = M; a.N = N; a.K = K; a.epi = epi; a.bias = bias; a.res = res; a.ldres = ldres; a.scale = 1.f;
+    return a;
+}
+
+inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
+
+struct Carver {
+    char* base; size_t off = 0;
+    explicit Carver(char* b) : base(b) {}
+    template <typename T> T* take(size_t n) { T* p = (T*)(base + off); off = align_up(off + n * sizeof(T)); return p; }
+};
+
+size_t image_ws_bytes(const ovmr_handle* h, long B) {
+    const long M = B * h->L, W = h->d.vision_width;
+    size_t s = 0;
+    s += align_up((size_t)B * h->G * h->G * h->Kpad * 2);
+    s += align_up((size_t)M * W * 2) * 2;          // x, y
+    s += align_up((size_t)M * 3 * W * 2);          // qkv
+    s += align_up((size_t)M * 4 * W * 2);          // mlp hidden
+    s += align_up((size_t)B * W * 2);              // CLS rows
+    return s;
+}
+size_t text_ws_bytes(const ovmr_handle* h, long N) {
+    const long M = N * h->d.context_length, W = h->d.transformer_width;
+    return align_up((size_t)M * W * 2) * 2 + align_up((size_t)M * 3 * W * 2) + align_up((size_t)M * 4 * W * 2) +
+           align_up((size_t)N * W * 2) + align_up((size_t)N * 4);
+}
+size_t agg_ws_bytes(const ovmr_handle* h, long rows) {
+    const long D = h->d.embed_dim;
+    return align_up((size_t)rows * D * 4) * 2 + align_up((size_t)rows * 3 * D * 4) + align_up((size_t)rows * 4 * D * 4);
+}
+
+// One pre-LN residual attention block (clip/model.py:191-194) on fp16 activations.
+int run_block_f16(ovmr_handle* h, const Block& k, half_t* x, half_t* y, half_t* qkv, half_t* hid,
+                  int nseq, int L, int W, int causal, hipStream_t s) {
+    const int M = nseq * L, H = W / 64;
+    CK(launch_layernorm(x, y, k.ln1_g, k.ln1_b, M, W, W, 0, s));
+    CK(launch_gemm_f16(gemm(y, W, k.in_w, W, qkv, 3 * W, M, 3 * W, W, EPI_BIAS, k.in_b), h->gemm_variant, s));
+    CK(launch_attention_f16(qkv, y, nseq, L, H, causal, h->attn_variant, s));
+    CK(launch_gemm_f16(gemm(y, W, k.out_w, W, x, W, M, W, W, EPI_BIAS_RES, k.out_b, x, W), h->gemm_variant, s));
+    CK(launch_layernorm(x, y, k.ln2_g, k.ln2_b, M, W, W, 0, s));
+    CK(launch_gemm_f16(gemm(y, W, k.fc_w, W, hid, 4 * W, M, 4 * W, W, EPI_BIAS_QGELU, k.fc_b), h->gemm_variant, s));
+    CK(launch_gemm_f16(gemm(hid, 4 * W, k.pj_w, 4 * W, x, W, M, W, 4 * W, EPI_BIAS_RES, k.pj_b, x, W), h->gemm_variant, s));
+    return 0;
+}
+
+// Same block in fp32 (ResidualAttentionBlockWithDropout in eval mode, clip/model.py:248-251).
+int run_block_f32(ovmr_handle* h, const Block& k, float* x, float* y, float* qkv, float* hid,
+                  int nseq, int L, int W, hipStream_t s) {
+    const int M = nseq * L, H = W / 64;
+    CK(launch_layernorm(x, y, k.ln1_g, k.ln1_b, M, W, W, 1, s));
+    CK(launch_gemm_f32(gemm(y, W, k.in_w, W, qkv, 3 * W, M, 3 * W, W, EPI_BIAS, k.in_b), s));
+    CK(launch_attention_f32(qkv, y, nseq, L, H, s));
+    CK(launch_gemm_f32(gemm(y, W, k.out_w, W, x, W, M, W, W, EPI_BIAS_RES, k.out_b, x, W), s));
+    CK(launch_layernorm(x, y, k.ln2_g, k.ln2_b, M, W, W, 1, s));
+    CK(launch_gemm_f32(gemm(y, W, k.fc_w, W, hid, 4 * W, M, 4 * W, W, EPI_BIAS_QGELU, k.fc_b), s));
+    CK(launch_gemm_f32(gemm(hid, 4 * W, k.pj_w, 4 * W, x, W, M, W, 4 * W, EPI_BIAS_RES, k.pj_b, x, W), s));
+    return 0;
+}
+
+int normalize_rows(ovmr_handle* h, half_t* x, int rows, int D, int mode, hipStream_t s) {
+    for (int i = 0; i < mode; ++i) CK(launch_l2norm_f16(x, rows, D, s));
+    return 0;
+}
+
+// Text tower after the embedding: blocks, gather, ln_final, projection (clip/model.py:824-831).
+int run_text_tower(ovmr_handle* h, half_t* x, half_t* y, half_t* qkv, half_t* hid, half_t* rows, const int* index,
+                   int N, int Ls, half_t* out, int normalize, hipStream_t s) {
+    const int W = h->d.transformer_width;
+    for (auto& k : h->txt) CK(run_block_f16(h, k, x, y, qkv, hid, N, Ls, W, 1, s));
+    CK(launch_gather_rows_f16(x, index, rows, N, Ls, W, s));
+    CK(launch_layernorm(rows, rows, h->ln_final_g, h->ln_final_b, N, W, W, 0, s));
+    CK(launch_gemm_f16(gemm(rows, W, h->textproj_t, W, out, h->d.embed_dim, N, h->d.embed_dim, W, EPI_NONE), h->gemm_variant, s));
+    return normalize_rows(h, out, N, h->d.embed_dim, normalize, s);
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* ovmr_version(void) { return "ovmr_hip 0.1 (gfx950)"; }
+
+int ovmr_create(const ovmr_model_desc* d, ovmr_handle** out) {
+    if (!d || !out) return OVMR_E_ARG;
+    if (d->vision_width % 64 || d->transformer_width % 64 || d->embed_dim % 64 || d->vision_patch_size <= 0 ||
+        d->image_resolution % d->vision_patch_size || d->n_ctx < 1 || d->context_length < 4 + d->n_ctx)
+        return OVMR_E_SHAPE;
+    ovmr_handle* h = new ovmr_handle();
+    h->d = *d;
+    h->G = d->image_resolution / d->vision_patch_size;
+    h->L = h->G * h->G + 1;
+    h->Kpad = (3 * d->vision_patch_size * d->vision_patch_size + 63) / 64 * 64;
+    *out = h;
+    return 0;
+}
+
+void ovmr_destroy(ovmr_handle* h) {
+    if (!h) return;
+    for (void* p : h->owned) (void)hipFree(p);
+    if (h->ws) (void)hipFree(h->ws);
+    delete h;
+}
+
+const char* ovmr_last_error(const ovmr_handle* h) { return h ? h->err.c_str() : "null handle"; }
+
+int ovmr_set_option(ovmr_handle* h, const char* key, int value) {
+    if (!h || !key) return OVMR_E_ARG;
+    if (!strcmp(key, "gemm")) h->gemm_variant = value;
+    else if (!strcmp(key, "attn")) h->attn_variant = value;
+    else return fail(h, OVMR_E_NAME, "unknown option '%s'", key);
+    return 0;
+}
+
+float ovmr_logit_scale(const ovmr_handle* h) { return h ? h->logit_scale_exp : 0.f; }
+
+int ovmr_set_weight(ovmr_handle* h, const char* name_c, const void* data, int dtype, int ndim,
+                    const int64_t* shape, ovmr_stream stream) {
+    if (!h || !name_c || !data || (dtype != OVMR_F16 && dtype != OVMR_F32) || ndim < 0 || ndim > 4) return OVMR_E_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    const std::string name(name_c);
+    size_t elems = 1;
+    for (int i = 0; i < ndim; ++i) elems *= (size_t)shape[i];
+    static const char* suffixes[] = {"attn.in_proj_weight", "attn.in_proj_bias", "attn.out_proj.weight", "attn.out_proj.bias",
+                                     "mlp.c_fc.weight", "mlp.c_fc.bias", "mlp.c_proj.weight", "mlp.c_proj.bias",
+                                     "ln_1.weight", "ln_1.bias", "ln_2.weight", "ln_2.bias"};
+    bool known = false;
+    if (name.rfind("visual.transformer.resblocks.", 0) == 0 || name.rfind("transformer.resblocks.", 0) == 0 ||
+        name.rfind("prompt_learner.aggregator.resblocks.", 0) == 0)
+        for (const char* sf : suffixes) known |= ends_with(name, sf);
+    static const char* singles[] = {"visual.class_embedding", "visual.positional_embedding", "visual.proj", "visual.conv1.weight",
+                                    "visual.ln_pre.weight", "visual.ln_pre.bias", "visual.ln_post.weight", "visual.ln_post.bias",
+                                    "token_embedding.weight", "positional_embedding", "ln_final.weight", "ln_final.bias",
+                                    "text_projection", "logit_scale", "prompt_learner.cls_token"};
+    for (const char* sn : singles) known |= (name == sn);
+    if (!known) return fail(h, OVMR_E_NAME, "unknown weight name '%s'", name_c);
+
+    if (name == "logit_scale") {
+        if (elems != 1) return fail(h, OVMR_E_SHAPE, "logit_scale must be a scalar");
+        float v = 0.f;
+        if (dtype == OVMR_F32) {
+            HIP_CHECK_RET(hipMemcpyAsync(&v, data, 4, hipMemcpyDeviceToHost, s));
+            HIP_CHECK_RET(hipStreamSynchronize(s));
+        } else {
+            half_t hv;
+            HIP_CHECK_RET(hipMemcpyAsync(&hv, data, 2, hipMemcpyDeviceToHost, s));
+            HIP_CHECK_RET(hipStreamSynchronize(s));
+            v = (float)hv;
+        }
+        h->logit_scale_exp = expf(v);     // logit_scale.exp(), trainers/mm_classifier_one_prompt.py:238,296
+        h->have_logit_scale = true;
+        return 0;
+    }
+    Buf& b = h->w[name];
+    b.f32 = stored_as_f32(name) ? 1 : 0;
+    if (!b.p || b.elems != elems) {
+        b.p = dev_alloc(h, elems * (b.f32 ? 4 : 2));
+        if (!b.p) return fail(h, OVMR_E_NOMEM, "hipMalloc failed for '%s'", name_c);
+    }
+    b.elems = elems;
+    b.shape.assign(shape, shape + ndim);
+    h->finalized = false;
+    return launch_cast(data, dtype == OVMR_F32, b.p, b.f32, (long)elems, s);
+}
+
+int ovmr_finalize(ovmr_handle* h, int max_images, int max_prompts, int max_classes, ovmr_stream stream) {
+    if (!h || max_images < 1 || max_prompts < 1 || max_classes < 1) return OVMR_E_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    const ovmr_model_desc& d = h->d;
+    const size_t W = d.vision_width, T = d.transformer_width, E = d.embed_dim, P = d.vision_patch_size;
+    if (!h->have_logit_scale) return fail(h, OVMR_E_STATE, "weight 'logit_scale' was never set");
+
+    if (int rc = bind_blocks(h, "visual.transformer.resblocks.", d.vision_layers, (int)W, h->vis)) return rc;
+    if (int rc = bind_blocks(h, "transformer.resblocks.", d.transformer_layers, (int)T, h->txt)) return rc;
+    if (int rc = bind_blocks(h, "prompt_learner.aggregator.resblocks.", d.agg_layers, (int)E, h->agg)) return rc;
+
+    const Buf *conv, *cls, *pos, *proj, *tpos, *tproj, *b;
+    if (!(conv = find(h, "visual.conv1.weight", W * 3 * P * P))) return OVMR_E_STATE;
+    if (!(cls = find(h, "visual.class_embedding", W))) return OVMR_E_STATE;
+    if (!(pos = find(h, "visual.positional_embedding", (size_t)h->L * W))) return OVMR_E_STATE;
+    if (!(proj = find(h, "visual.proj", W * E))) return OVMR_E_STATE;
+    if (!(tpos = find(h, "positional_embedding", (size_t)d.context_length * T))) return OVMR_E_STATE;
+    if (!(tproj = find(h, "text_projection", T * E))) return OVMR_E_STATE;
+#define BINDF(field, nm, n) if (!(b = find(h, nm, n))) return OVMR_E_STATE; h->field = (float*)b->p;
+    BINDF(ln_pre_g, "visual.ln_pre.weight", W) BINDF(ln_pre_b, "visual.ln_pre.bias", W)
+    BINDF(ln_post_g, "visual.ln_post.weight", W) BINDF(ln_post_b, "visual.ln_post.bias", W)
+    BINDF(ln_final_g, "ln_final.weight", T) BINDF(ln_final_b, "ln_final.bias", T)
+    BINDF(tok_emb, "token_embedding.weight", (size_t)d.vocab_size * T)
+    BINDF(cls_token, "prompt_learner.cls_token", (size_t)d.n_ctx * E)
+#undef BINDF
+
+    // derived layouts
+    h->conv_w = (half_t*)dev_alloc(h, W * h->Kpad * 2);
+    h->pos16_vis = (half_t*)dev_alloc(h, (size_t)h->L * W * 2);
+    h->cls_pos16 = (half_t*)dev_alloc(h, W * 2);
+    h->proj_t = (half_t*)dev_alloc(h, E * W * 2);
+    h->pos16_txt = (half_t*)dev_alloc(h, (size_t)d.context_length * T * 2);
+    h->textproj_t = (half_t*)dev_alloc(h, E * T * 2);
+    half_t* cls16 = (half_t*)dev_alloc(h, W * 2);
+    if (!h->conv_w || !h->pos16_vis || !h->cls_pos16 || !h->proj_t || !h->pos16_txt || !h->textproj_t || !cls16)
+        return fail(h, OVMR_E_NOMEM, "hipMalloc failed for derived weights");
+    CK(launch_pad_rows_f16((const half_t*)conv->p, h->conv_w, (int)W, (int)(3 * P * P), h->Kpad, s));
+    CK(launch_cast(pos->p, 1, h->pos16_vis, 0, (long)h->L * W, s));            // positional_embedding.to(fp16), clip/model.py:416
+    CK(launch_cast(cls->p, 1, cls16, 0, (long)W, s));                          // class_embedding.to(fp16), :415
+    CK(launch_add_f16(cls16, h->pos16_vis, h->cls_pos16, (long)W, s));
+    CK(launch_transpose_to_f16(proj->p, 0, h->proj_t, (int)W, (int)E, s));     // x @ proj == x * proj^T^T
+    CK(launch_cast(tpos->p, 1, h->pos16_txt, 0, (long)d.context_length * T, s));
+    CK(launch_transpose_to_f16(tproj->p, 0, h->textproj_t, (int)T, (int)E, s));
+
+    // workspace: one arena, re-carved by each entry point (calls on one handle are stream ordered)
+    h->max_images = max_images; h->max_prompts = max_prompts; h->max_classes = max_classes;
+    h->agg_rows_cap = (long)max_classes * (d.n_ctx + 32);
+    h->logit_elems_cap = 32L << 20;
+    size_t need = image_ws_bytes(h, max_images);
+    need = std::max(need, text_ws_bytes(h, max_prompts));
+    need = std::max(need, agg_ws_bytes(h, h->agg_rows_cap));
+    need = std::max(need, align_up((size_t)h->logit_elems_cap * 2) * 3 + align_up((size_t)65536 * E * 2));
+    if (need > h->ws_bytes) {
+        if (h->ws) (void)hipFree(h->ws);
+        h->ws = nullptr;
+        if (hipMalloc((void**)&h->ws, need) != hipSuccess) return fail(h, OVMR_E_NOMEM, "workspace of %zu bytes", need);
+        h->ws_bytes = need;
+    }
+    HIP_CHECK_RET(hipStreamSynchronize(s));
+    h->finalized = true;
+    return 0;
+}
+
+int ovmr_encode_image(ovmr_handle* h, const void* image, int image_dtype, int B, void* out_f16, int normalize,
+                      ovmr_stream stream) {
+    if (!h || !image || !out_f16 || B < 0 || (image_dtype != OVMR_F16 && image_dtype != OVMR_F32)) return OVMR_E_ARG;
+    if (!h->finalized) return fail(h, OVMR_E_STATE, "ovmr_finalize() has not been called");
+    hipStream_t s = (hipStream_t)stream;
+    const ovmr_model_desc& d = h->d;
+    const int W = d.vision_width, R = d.image_resolution, L = h->L, G2 = h->G * h->G, E = d.embed_dim;
+    const size_t px = (size_t)3 * R * R * (image_dtype == OVMR_F32 ? 4 : 2);
+    for (int b0 = 0; b0 < B; b0 += h->max_images) {
+        const int Bc = std::min(h->max_images, B - b0);
+        const int M = Bc * L;
+        Carver c(h->ws);
+        half_t* col = c.take<half_t>((size_t)Bc * G2 * h->Kpad);
+        half_t* x = c.take<half_t>((size_t)M * W);
+        half_t* y = c.take<half_t>((size_t)M * W);
+        half_t* qkv = c.take<half_t>((size_t)M * 3 * W);
+        half_t* hid = c.take<half_t>((size_t)M * 4 * W);
+        half_t* rows = c.take<half_t>((size_t)Bc * W);
+        half_t* out = (half_t*)out_f16 + (size_t)b0 * E;
+        // K1/K2: conv1 as GEMM over patches, positional add in the epilogue, CLS row, ln_pre
+        CK(launch_im2col((const char*)image + (size_t)b0 * px, image_dtype == OVMR_F32, col, Bc, R, d.vision_patch_size, h->Kpad, s));
+        GemmArgs pe = gemm(col, h->Kpad, h->conv_w, h->Kpad, x, W, Bc * G2, W, h->Kpad, EPI_PATCH);
+        pe.pos = h->pos16_vis; pe.rows_in = G2; pe.rows_out = L;
+        CK(launch_gemm_f16(pe, h->gemm_variant, s));
+        CK(launch_fill_cls(x, h->cls_pos16, Bc, L, W, s));
+        CK(launch_layernorm(x, x, h->ln_pre_g, h->ln_pre_b, M, W, W, 0, s));
+        for (auto& k : h->vis) CK(run_block_f16(h, k, x, y, qkv, hid, Bc, L, W, 0, s));
+        // K9: ln_post on the CLS rows, projection; K10: normalise
+        CK(launch_layernorm(x, rows, h->ln_post_g, h->ln_post_b, Bc, W, (long)L * W, 0, s));
+        CK(launch_gemm_f16(gemm(rows, W, h->proj_t, W, out, E, Bc, E, W, EPI_NONE), h->gemm_variant, s));
+        CK(normalize_rows(h, out, Bc, E, normalize ? 1 : 0, s));
+    }
+    return 0;
+}
+
+int ovmr_encode_text_embedded(ovmr_handle* h, const void* prompts_f16, const int32_t* index, int N, int seq_len,
+                              void* out_f16, int normalize, ovmr_stream stream) {
+    if (!h || !prompts_f16 || !index || !out_f16 || N < 0 || normalize < 0 || normalize > 2) return OVMR_E_ARG;
+    if (!h->finalized) return fail(h, OVMR_E_STATE, "ovmr_finalize() has not been called");
+    const ovmr_model_desc& d = h->d;
+    if (seq_len < 1 || seq_len > d.context_length) return fail(h, OVMR_E_ARG, "seq_len %d outside [1,%d]", seq_len, d.context_length);
+    hipStream_t s = (hipStream_t)stream;
+    const int W = d.transformer_width, Lc = d.context_length, E = d.embed_dim;
+    for (int n0 = 0; n0 < N; n0 += h->max_prompts) {
+        const int Nc = std::min(h->max_prompts, N - n0);
+        const size_t M = (size_t)Nc * seq_len;
+        Carver c(h->ws);
+        half_t* x = c.take<half_t>(M * W);
+        half_t* y = c.take<half_t>(M * W);
+        half_t* qkv = c.take<half_t>(M * 3 * W);
+        half_t* hid = c.take<half_t>(M * 4 * W);
+        half_t* rows = c.take<half_t>((size_t)Nc * W);
+        CK(launch_text_add_pos((const half_t*)prompts_f16 + (size_t)n0 * Lc * W, Lc, h->pos16_txt, x, Nc, seq_len, W, s));
+        CK(run_text_tower(h, x, y, qkv, hid, rows, index + n0, Nc, seq_len, (half_t*)out_f16 + (size_t)n0 * E, normalize, s));
+    }
+    return 0;
+}
+
+int ovmr_encode_text_ids(ovmr_handle* h, const int64_t* ids, int N, int seq_len, void* out_f16, int normalize,
+                         ovmr_stream stream) {
+    if (!h || !ids || !out_f16 || N < 0 || normalize < 0 || normalize > 2) return OVMR_E_ARG;
+    if (!h->finalized) return fail(h, OVMR_E_STATE, "ovmr_finalize() has not been called");
+    const ovmr_model_desc& d = h->d;
+    if (seq_len < 1 || seq_len > d.context_length) return fail(h, OVMR_E_ARG, "seq_len %d outside [1,%d]", seq_len, d.context_length);
+    hipStream_t s = (hipStream_t)stream;
+    const int W = d.transformer_width, Lc = d.context_length, E = d.embed_dim;
+    for (int n0 = 0; n0 < N; n0 += h->max_prompts) {
+        const int Nc = std::min(h->max_prompts, N - n0);
+        const size_t M = (size_t)Nc * seq_len;
+        Carver c(h->ws);
+        half_t* x = c.take<half_t>(M * W);
+        half_t* y = c.take<half_t>(M * W);
+        half_t* qkv = c.take<half_t>(M * 3 * W);
+        half_t* hid = c.take<half_t>(M * 4 * W);
+        half_t* rows = c.take<half_t>((size_t)Nc * W);
+        int* index = c.take<int>((size_t)Nc);
+        CK(launch_text_embed_ids(ids + (size_t)n0 * Lc, Lc, h->tok_emb, h->pos16_txt, x, index, Nc, Lc, seq_len, W, s));
+        CK(run_text_tower(h, x, y, qkv, hid, rows, index, Nc, seq_len, (half_t*)out_f16 + (size_t)n0 * E, normalize, s));
+    }
+    return 0;
+}
+
+int ovmr_embed_tokens(ovmr_handle* h, const int64_t* ids, int N, int L, void* out_f16, ovmr_stream stream) {
+    if (!h || !ids || !out_f16 || N < 0 || L < 1) return OVMR_E_ARG;
+    if (!h->finalized) return fail(h, OVMR_E_STATE, "ovmr_finalize() has not been called");
+    return launch_embed_gather(ids, h->tok_emb, (half_t*)out_f16, (long)N * L, h->d.transformer_width, (hipStream_t)stream);
+}
+
+int ovmr_generate_tokens(ovmr_handle* h, const void* feats_f16, int Cb, int S, float* tokens_f32, ovmr_stream stream) {
+    if (!h || !feats_f16 || !tokens_f32 || Cb < 0 || S < 1) return OVMR_E_ARG;
+    if (!h->finalized) return fail(h, OVMR_E_STATE, "ovmr_finalize() has not been called");
+    const ovmr_model_desc& d = h->d;
+    const int D = d.embed_dim, La = d.n_ctx + S;
+    if (La > 128) return fail(h, OVMR_E_SHAPE, "n_ctx + shots = %d exceeds 128", La);
+    hipStream_t s = (hipStream_t)stream;
+    const int chunk = (int)std::max(1L, h->agg_rows_cap / La);
+    for (int c0 = 0; c0 < Cb; c0 += chunk) {
+        const int Cc = std::min(chunk, Cb - c0);
+        const size_t M = (size_t)Cc * La;
+        Carver c(h->ws);
+        float* x = c.take<float>(M * D);
+        float* y = c.take<float>(M * D);
+        float* qkv = c.take<float>(M * 3 * D);
+        float* hid = c.take<float>(M * 4 * D);
+        CK(launch_agg_input(h->cls_token, (const half_t*)feats_f16 + (size_t)c0 * S * D, x, Cc, S, d.n_ctx, D, s));
+        for (auto& k : h->agg) CK(run_block_f32(h, k, x, y, qkv, hid, Cc, La, D, s));
+        CK(launch_agg_output(x, tokens_f32 + (size_t)c0 * d.n_ctx * D, Cc, La, d.n_ctx, D, s));
+    }
+    return 0;
+}
+
+int ovmr_assemble_prompts(ovmr_handle* h, const void* base_f16, const int64_t* labels, const float* tokens_f32, int Cb,
+                          void* out_f16, ovmr_stream stream) {
+    if (!h || !base_f16 || !tokens_f32 || !out_f16 || Cb < 0) return OVMR_E_ARG;
+    if (!h->finalized) return fail(h, OVMR_E_STATE, "ovmr_finalize() has not been called");
+    if (h->d.embed_dim != h->d.transformer_width)
+        return fail(h, OVMR_E_SHAPE, "visual tokens (embed_dim %d) do not fit the text width %d", h->d.embed_dim, h->d.transformer_width);
+    CK(launch_assemble_prompts((const half_t*)base_f16, labels, tokens_f32, (half_t*)out_f16, Cb, h->d.context_length,
+                               h->d.n_ctx, h->d.transformer_width, (hipStream_t)stream));
+    return 0;
+}
+
+int ovmr_xval_counts(ovmr_handle* h, const void* feats_f16, const int32_t* labels, int R, const void* clf_f16, int C,
+                     int32_t* tp, int32_t* n_pred, ovmr_stream stream) {
+    if (!h || !feats_f16 || !labels || !clf_f16 || !tp || !n_pred || R < 0 || C < 1) return OVMR_E_ARG;
+    if (!h->finalized) return fail(h, OVMR_E_STATE, "ovmr_finalize() has not been called");
+    hipStream_t s = (hipStream_t)stream;
+    const int D = h->d.embed_dim;
+    const int chunk = (int)std::min<long>(std::max<long>(64, h->logit_elems_cap / C), 1L << 20);
+    Carver c(h->ws);
+    half_t* logits = c.take<half_t>((size_t)h->logit_elems_cap);
+    for (int r0 = 0; r0 < R; r0 += chunk) {
+        const int Rc = std::min(chunk, R - r0);
+        if ((long)Rc * C > h->logit_elems_cap) return fail(h, OVMR_E_SHAPE, "class count %d too large for the logits workspace", C);
+        GemmArgs g = gemm((const half_t*)feats_f16 + (size_t)r0 * D, D, clf_f16, D, logits, C, Rc, C, D, EPI_SCALE);
+        g.scale = h->logit_scale_exp;
+        CK(launch_gemm_f16(g, h->gemm_variant, s));
+        CK(launch_argmax_counts(logits, C, labels + r0, Rc, C, tp, n_pred, s));
+    }
+    return 0;
+}
+
+int ovmr_fusion_weights(ovmr_handle* h, const int32_t* counts, const int32_t* n_label, int C, float tau, float* out_f32,
+                        ovmr_stream stream) {
+    if (!h || !counts || !n_label || !out_f32 || C < 1) return OVMR_E_ARG;
+    CK(launch_fusion_weights(counts, n_label, C, tau, out_f32, (hipStream_t)stream));
+    return 0;
+}
+
+int ovmr_fused_logits(ovmr_handle* h, const void* feats_f16, int B, const void* mm, const void* v, const void* t,
+                      const float* w, int C, int mode, float* out_f32, ovmr_stream stream) {
+    if (!h || !feats_f16 || !out_f32 || B < 0 || C < 1) return OVMR_E_ARG;
+    if (!h->finalized) return fail(h, OVMR_E_STATE, "ovmr_finalize() has not been called");
+    hipStream_t s = (hipStream_t)stream;
+    const int D = h->d.embed_dim;
+    const void* clf[3];
+    int n_mod;
+    switch (mode) {
+        case OVMR_MODE_FUSION: clf[0] = mm; clf[1] = v; clf[2] = t; n_mod = 3; if (!w) return OVMR_E_ARG; break;   // column order mm, v, t (:361)
+        case OVMR_MODE_TEXT: clf[0] = t; n_mod = 1; break;
+        case OVMR_MODE_VISION: clf[0] = v; n_mod = 1; break;
+        case OVMR_MODE_MULTIMODAL: clf[0] = mm; n_mod = 1; break;
+        default: return fail(h, OVMR_E_ARG, "unknown eval mode %d", mode);
+    }
+    for (int m = 0; m < n_mod; ++m) if (!clf[m]) return fail(h, OVMR_E_ARG, "classifier %d is NULL for mode %d", m, mode);
+    const int chunk = (int)std::min<long>(std::max<long>(1, h->logit_elems_cap / C), 65536);
+    for (int b0 = 0; b0 < B; b0 += chunk) {
+        const int Bc = std::min(chunk, B - b0);
+        Carver c(h->ws);
+        half_t* l[3] = {nullptr, nullptr, nullptr};
+        for (int m = 0; m < 3; ++m) l[m] = c.take<half_t>((size_t)h->logit_elems_cap);
+        half_t* sf = c.take<half_t>((size_t)65536 * D);
+        // (logit_scale * image_features) is rounded to fp16 before the matmul (:358-360)
+        CK(launch_scale_f16((const half_t*)feats_f16 + (size_t)b0 * D, sf, h->logit_scale_exp, (long)Bc * D, s));
+        for (int m = 0; m < n_mod; ++m)
+            CK(launch_gemm_f16(gemm(sf, D, clf[m], D, l[m], C, Bc, C, D, EPI_NONE), h->gemm_variant, s));
+        CK(launch_fused_softmax(l[0], n_mod > 1 ? l[1] : nullptr, n_mod > 2 ? l[2] : nullptr,
+                                mode == OVMR_MODE_FUSION ? w : nullptr, n_mod, out_f32 + (size_t)b0 * C, Bc, C, s));
+    }
+    return 0;
+}
+
+int ovmr_zeroshot_logits(ovmr_handle* h, const void* feats_f16, int B, const void* text_f16, int C, void* out_f16,
+                         ovmr_stream stream) {
+    if (!h || !feats_f16 || !text_f16 || !out_f16 || B < 0 || C < 1) return OVMR_E_ARG;
+    if (!h->finalized) return fail(h, OVMR_E_STATE, "ovmr_finalize() has not been called");
+    hipStream_t s = (hipStream_t)stream;
+    const int D = h->d.embed_dim;
+    for (int b0 = 0; b0 < B; b0 += 65536) {
+        const int Bc = std::min(65536, B - b0);
+        Carver c(h->ws);
+        half_t* sf = c.take<half_t>((size_t)65536 * D);
+        CK(launch_scale_f16((const half_t*)feats_f16 + (size_t)b0 * D, sf, h->logit_scale_exp, (long)Bc * D, s));
+        CK(launch_gemm_f16(gemm(sf, D, text_f16, D, (half_t*)out_f16 + (size_t)b0 * C, C, Bc, C, D, EPI_NONE), h->gemm_variant, s));
+    }
+    return 0;
+}
+
+// Closed-form FLOPs (2*MAC), SURVEY.md section 2.3: per layer 24*L*W^2 (QKV 6, out 2, MLP 16) + 4*L^2*W
+static double tower_flops(double L, double W, double layers) { return layers * (24.0 * L * W * W + 4.0 * L * L * W); }
+
+double ovmr_flops_per_image(const ovmr_handle* h) {
+    if (!h) return 0;
+    const ovmr_model_desc& d = h->d;
+    const double G2 = (double)h->G * h->G, W = d.vision_width, K = 3.0 * d.vision_patch_size * d.vision_patch_size;
+    return 2.0 * G2 * K * W + tower_flops(h->L, W, d.vision_layers) + 2.0 * W * d.embed_dim;
+}
+double ovmr_flops_per_prompt(const ovmr_handle* h, int seq_len) {
+    if (!h) return 0;
+    const ovmr_model_desc& d = h->d;
+    return tower_flops(seq_len, d.transformer_width, d.transformer_layers) + 2.0 * d.transformer_width * d.embed_dim;
+}
+
+}  // extern "C"
+
+// ---- unit-test hooks (tests/test_hip_kernels.py): one kernel per call, no handle state -----------
+extern "C" {
+
+int ovmr_debug_gemm(int f32, int variant, const void* A, const void* W, const void* bias, const void* res,
+                    const void* pos, void* C, int M, int N, int K, int ldc, int epi, float scale,
+                    int rows_in, int rows_out, ovmr_stream stream) {
+    GemmArgs a = gemm(A, K, W, K, C, ldc, M, N, K, epi, bias, res, ldc);
+    a.pos = pos; a.scale = scale; a.rows_in = rows_in; a.rows_out = rows_out;
+    return f32 ? launch_gemm_f32(a, (hipStream_t)stream) : launch_gemm_f16(a, variant, (hipStream_t)stream);
+}
+
+int ovmr_debug_layernorm(int f32, const void* x, void* y, const float* g, const float* b, int rows, int D,
+                         long in_stride, ovmr_stream stream) {
+    return launch_layernorm(x, y, g, b, rows, D, in_stride, f32, (hipStream_t)stream);
+}
+
+int ovmr_debug_attention(int f32, int variant, const void* qkv, void* out, int B, int L, int H, int causal,
+                         ovmr_stream stream) {
+    return f32 ? launch_attention_f32((const float*)qkv, (float*)out, B, L, H, (hipStream_t)stream)
+               : launch_attention_f16((const half_t*)qkv, (half_t*)out, B, L, H, causal, variant, (hipStream_t)stream);
+}
+
+}  // extern "C"

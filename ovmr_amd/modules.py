@@ -1,0 +1,405 @@
+"""Host-side mirror of the reference's module API for the OVMR hot path (orchestration only).
+
+Same names, argument meaning, return types and file formats as
+trainers/mm_classifier_one_prompt.py (`TextEncoder` :63-91, `PromptLearner` :94-176,
+`CustomCLIP` :179-364) and clip/model.py:`build_model` (:899-936); every piece of arithmetic is
+a call into libovmr_hip.so through ovmr_amd.runtime.Engine.  Nothing here computes on the CPU and
+nothing falls back when the HIP library or the GPU is missing.
+
+Differences a reference user will notice (all documented in DESIGN.md):
+  * `clip_model` is a `CLIPModel` (weights + architecture), not an nn.Module;
+  * class names need a tokenizer: pass `tokenizer=` (an object with the reference
+    SimpleTokenizer's `encode(str) -> list[int]`) or pass already tokenised prompts
+    (LongTensor [C, 77]) in place of `classnames`;
+  * the training branch of CustomCLIP.forward (:310-338) is out of scope and raises;
+  * with torch.distributed initialised, forward_prompt shards the eval-set batches over ranks,
+    all-gathers the classifier rows (RCCL) and all-reduces the F1 counters.
+"""
+from __future__ import annotations
+
+import os
+import os.path as osp
+from types import SimpleNamespace
+from typing import Dict, Iterable, List, Optional, Sequence, Union
+
+import numpy as np
+import torch
+
+from . import synth
+from .runtime import Engine
+from .synth import ModelSpec, SOT_ID, EOT_ID
+
+
+# ----------------------------------------------------------------------------- CLIP weights
+def infer_spec(state_dict: Dict[str, torch.Tensor], name: str = "from_state_dict") -> ModelSpec:
+    """Architecture inference of build_model(), clip/model.py:899-928 (ViT branch only)."""
+    if "visual.proj" not in state_dict:
+        raise ValueError("only ViT CLIP models are on the hot path (ModifiedResNet is out of scope)")
+    vision_width = state_dict["visual.conv1.weight"].shape[0]
+    vision_layers = len([k for k in state_dict if k.startswith("visual.") and k.endswith(".attn.in_proj_weight")])
+    patch = state_dict["visual.conv1.weight"].shape[-1]
+    grid = round((state_dict["visual.positional_embedding"].shape[0] - 1) ** 0.5)
+    embed_dim = state_dict["text_projection"].shape[1]
+    context_length = state_dict["positional_embedding"].shape[0]
+    vocab_size = state_dict["token_embedding.weight"].shape[0]
+    width = state_dict["ln_final.weight"].shape[0]
+    layers = len(set(k.split(".")[2] for k in state_dict if k.startswith("transformer.resblocks")))
+    return ModelSpec(name, embed_dim, patch * grid, vision_layers, vision_width, patch, context_length,
+                     vocab_size, width, width // 64, layers)
+
+
+class CLIPModel:
+    """Stands where the reference passes `clip_model`: weights in the reference state-dict layout."""
+
+    def __init__(self, state_dict: Dict[str, "torch.Tensor"], spec: Optional[ModelSpec] = None,
+                 device: str = "cuda:0"):
+        self._sd = {k: (torch.from_numpy(v) if isinstance(v, np.ndarray) else v) for k, v in state_dict.items()}
+        self.spec = spec or infer_spec(self._sd)
+        self.device = torch.device(device)
+        self.dtype = torch.float16                      # convert_weights(), clip/model.py:934
+        self.visual = SimpleNamespace(output_dim=self.spec.embed_dim, input_resolution=self.spec.image_resolution)
+        self.logit_scale = self._sd["logit_scale"].float()
+        self.context_length = self.spec.context_length
+        self.vocab_size = self.spec.vocab_size
+        self._engines: Dict[int, Engine] = {}
+
+    def state_dict(self):
+        return self._sd
+
+    def engine(self, n_ctx: int) -> Engine:
+        if n_ctx not in self._engines:
+            e = Engine(self.spec, n_ctx, str(self.device))
+            e.load_state_dict(self._sd)
+            self._engines[n_ctx] = e
+        return self._engines[n_ctx]
+
+    # CLIP.encode_image / encode_text (clip/model.py:814-833), used by the zero-shot baseline
+    def encode_image(self, image, n_ctx: int = 2):
+        return _ensure_final(self.engine(n_ctx)).encode_image(image, normalize=False)
+
+    def encode_text(self, text, n_ctx: int = 2):
+        return _ensure_final(self.engine(n_ctx)).encode_text_ids(text, normalize=0)
+
+
+def build_model(state_dict: Dict[str, "torch.Tensor"], device: str = "cuda:0") -> CLIPModel:
+    """clip/model.py:899-936."""
+    return CLIPModel(state_dict, None, device)
+
+
+def _ensure_final(e: Engine) -> Engine:
+    if not e.finalized:
+        if not hasattr(e, "_pl_loaded"):
+            raise RuntimeError("prompt-learner weights have not been loaded into the engine yet")
+        e.finalize(*getattr(e, "_reserve", (256, 256, 1024)))
+    return e
+
+
+def make_cfg(n_ctx: int = 2, num_shots: int = 16, eval_mode: str = "fusion", eval_tau: float = 10.0,
+             output_dir: str = "output_ovmr/generated_classifiers", backbone: str = "ViT-B/16",
+             test_batch_size: int = 256, size: int = 224) -> SimpleNamespace:
+    """The cfg keys the hot path reads, as a plain namespace tree (no yacs)."""
+    return SimpleNamespace(
+        TRAINER=SimpleNamespace(COCOOP=SimpleNamespace(N_CTX=n_ctx, PREC="fp16")),
+        INPUT=SimpleNamespace(SIZE=(size, size)),
+        DATALOADER=SimpleNamespace(TRAIN_X=SimpleNamespace(BATCH_SIZE=1536, N_INS=8), K_TRANSFORMS=1,
+                                   TEST=SimpleNamespace(BATCH_SIZE=test_batch_size)),
+        DATASET=SimpleNamespace(NUM_SHOTS=num_shots),
+        MODEL=SimpleNamespace(BACKBONE=SimpleNamespace(NAME=backbone), INIT_WEIGHTS=""),
+        EVAL_MODE=eval_mode, EVAL_TAU=eval_tau, OUTPUT_DIR=output_dir, SEED=1)
+
+
+def tokenize(texts: Sequence[str], tokenizer, context_length: int = 77) -> torch.Tensor:
+    """clip.tokenize (clip/clip.py:187-223) on top of a caller-supplied BPE `tokenizer.encode`."""
+    out = torch.zeros(len(texts), context_length, dtype=torch.long)
+    for i, t in enumerate(texts):
+        ids = [SOT_ID] + list(tokenizer.encode(t)) + [EOT_ID]
+        if len(ids) > context_length:
+            raise RuntimeError(f"Input {t} is too long for context length {context_length}")
+        out[i, :len(ids)] = torch.tensor(ids)
+    return out
+
+
+# ----------------------------------------------------------------------------- TextEncoder
+class TextEncoder:
+    """trainers/mm_classifier_one_prompt.py:63-91."""
+
+    def __init__(self, clip_model: CLIPModel, n_ctx: int = 2):
+        self.clip_model = clip_model
+        self.n_ctx = n_ctx
+        self.dtype = torch.float16                     # hard-coded in the reference (:70)
+
+    def forward(self, prompts: torch.Tensor, eos_index: torch.Tensor, seq_len: Optional[int] = None) -> torch.Tensor:
+        e = _ensure_final(self.clip_model.engine(self.n_ctx))
+        return e.encode_text_embedded(prompts, eos_index, seq_len, normalize=0)
+
+    __call__ = forward
+
+
+# ----------------------------------------------------------------------------- PromptLearner
+class PromptLearner:
+    """trainers/mm_classifier_one_prompt.py:94-176 (inference path)."""
+
+    def __init__(self, cfg, classnames, clip_model: CLIPModel, tokenizer=None,
+                 state_dict: Optional[Dict[str, "torch.Tensor"]] = None, compute_zero_shot: bool = True,
+                 reserve=(256, 256, 1024)):
+        self.cfg = cfg
+        self.n_ctx = n_ctx = cfg.TRAINER.COCOOP.N_CTX
+        self.dtype = torch.float16
+        spec = clip_model.spec
+        self.clip_model = clip_model
+        self.engine = e = clip_model.engine(n_ctx)
+        e._reserve = reserve
+        dev = e.device
+        if isinstance(classnames, torch.Tensor) or isinstance(classnames, np.ndarray):
+            tokenized = torch.as_tensor(classnames).long()
+            self.name_lens = (tokenized.argmax(-1) - 3).tolist()
+        else:
+            if tokenizer is None:
+                raise ValueError("class names need `tokenizer=` (reference SimpleTokenizer-compatible encode()); "
+                                 "alternatively pass tokenised prompts [C,77] instead of names")
+            names = [n.replace("_", " ") for n in classnames]                       # :109
+            self.name_lens = [len(tokenizer.encode(n)) for n in names]              # :110
+            tokenized = tokenize(["a " + n + "." for n in names], tokenizer, spec.context_length)   # :113,116
+        self.num_class = self.n_cls = tokenized.shape[0]
+        self._tokenized_host = tokenized
+        self._eos_host = tokenized.argmax(-1)
+        self.max_eos = int(self._eos_host.max())
+        self.tokenized_prompts = tokenized.to(dev)
+        self.eos_index = self._eos_host.to(dev)
+        vt = torch.from_numpy(synth.template_token_ids(spec.context_length))        # "a ." (:114-115)
+
+        # trainable state: cls_token + aggregator; random CLIP-style init when absent (:145-154)
+        if state_dict is None:
+            state_dict = {k: torch.from_numpy(v) for k, v in synth.prompt_learner_state_dict(spec, n_ctx, cfg.SEED).items()}
+        self._state: Dict[str, torch.Tensor] = {}
+        self.load_state_dict(state_dict, strict=True)
+        _ensure_final(e)
+
+        self.prompt_tokens = e.embed_tokens(self.tokenized_prompts)                 # :129,131
+        self.visual_prompt_temp = e.embed_tokens(vt.to(dev))                        # :130
+        self.zero_shot_classifier = None
+        if compute_zero_shot and self.num_class < 5000:                             # :118
+            self.zero_shot_classifier = self.encode_zero_shot(self.tokenized_prompts)
+
+    def encode_zero_shot(self, tokenized: torch.Tensor) -> torch.Tensor:
+        """:118-126 -- per class encode_text of its prompt, mean over the single prompt, F.normalize."""
+        return self.engine.encode_text_ids(tokenized, seq_len=self.max_eos + 1, normalize=1)
+
+    # nn.Module-like state API
+    def state_dict(self) -> Dict[str, torch.Tensor]:
+        return dict(self._state)
+
+    def load_state_dict(self, state_dict, strict: bool = False):
+        expected = set(synth.prompt_learner_keys(self.clip_model.spec))
+        sd = {k: v for k, v in state_dict.items() if k not in ("token_prefix", "token_suffix")}     # :482-487
+        unknown = set(sd) - expected
+        missing = expected - set(sd) - set(self._state)
+        if strict and (unknown or missing):
+            raise RuntimeError(f"PromptLearner.load_state_dict: missing {sorted(missing)}, unexpected {sorted(unknown)}")
+        for k, v in sd.items():
+            if k in expected:
+                t = (torch.from_numpy(v) if isinstance(v, np.ndarray) else v).detach().float()
+                self._state[k] = t
+                self.engine.set_weight("prompt_learner." + k, t)
+        self.engine._pl_loaded = True
+        if not missing:
+            self.engine.finalize(*self.engine._reserve)
+        return SimpleNamespace(missing_keys=sorted(missing), unexpected_keys=sorted(unknown))
+
+    @property
+    def cls_token(self):
+        return self._state["cls_token"]
+
+    def eval(self):
+        return self
+
+    training = False
+
+    def update_prompts(self, prompt_tokens, ins_tokens):
+        """:156-157 (kept for API parity; forward uses the fused assemble kernel)."""
+        return torch.cat([prompt_tokens[:, :2], ins_tokens.type(self.prompt_tokens.dtype),
+                          prompt_tokens[:, 2:-self.n_ctx]], dim=1)
+
+    def forward(self, exemplar_img_feats: torch.Tensor, label: torch.Tensor, ori_text_len: torch.Tensor):
+        """:159-176 -> (mm_prompts_list, mm_lens, v_prompts_list, v_lens, agg_img_token_)."""
+        e = self.engine
+        mm_lens = ori_text_len + self.n_ctx                                                     # :163
+        v_lens = torch.ones_like(ori_text_len, dtype=torch.int32) + self.n_ctx                  # :165
+        tokens = e.generate_tokens(exemplar_img_feats)                                          # :167-169
+        mm = e.assemble_prompts(self.prompt_tokens, label, tokens)                              # :171
+        v = e.assemble_prompts(self.visual_prompt_temp, None, tokens)                           # :173
+        return [mm], mm_lens, [v], v_lens, tokens
+
+    __call__ = forward
+
+
+# ----------------------------------------------------------------------------- CustomCLIP
+class _ImageEncoder:
+    """clip_model.visual as CustomCLIP uses it: callable, with .output_dim (:184, :216)."""
+
+    def __init__(self, engine: Engine):
+        self.engine = engine
+        self.output_dim = engine.spec.embed_dim
+
+    def __call__(self, image):
+        return self.engine.encode_image(image, normalize=False)
+
+
+class CustomCLIP:
+    """trainers/mm_classifier_one_prompt.py:179-364 (evaluation / classifier-generation branch)."""
+
+    def __init__(self, cfg, classnames, clip_model: CLIPModel, tokenizer=None,
+                 prompt_learner_state: Optional[Dict] = None, reserve=None):
+        self.cfg = cfg
+        import torch.distributed as dist
+        self._dist = dist if (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1) else None
+        if reserve is None:
+            reserve = (cfg.DATALOADER.TEST.BATCH_SIZE if hasattr(cfg.DATALOADER, "TEST") else 256, 256, 1024)
+        self.prompt_learner = PromptLearner(cfg, classnames, clip_model, tokenizer, prompt_learner_state,
+                                            compute_zero_shot=self._dist is None, reserve=reserve)
+        self.engine = self.prompt_learner.engine
+        self.tokenized_prompts = self.prompt_learner.tokenized_prompts
+        self.image_encoder = _ImageEncoder(self.engine)
+        self.text_encoder = TextEncoder(clip_model, self.prompt_learner.n_ctx)
+        self.logit_scale = clip_model.logit_scale
+        self.dtype = clip_model.dtype
+        self.train_bs = cfg.DATALOADER.TRAIN_X.BATCH_SIZE
+        self.num_ins = cfg.DATALOADER.TRAIN_X.N_INS
+        self.test_num_ins = cfg.DATASET.NUM_SHOTS
+        self.aug_times = cfg.DATALOADER.K_TRANSFORMS
+        self.zero_shot_classifier = self.prompt_learner.zero_shot_classifier
+        self.mm_classifier = None
+        self.visual_classifer = None          # sic -- attribute name of the reference (:225)
+        self.fusion_weight = None
+        self.device = self.engine.device
+
+    def eval(self):
+        return self
+
+    # :200-212
+    def get_mm_v_feats(self, mm_prompts, mm_lens, v_prompts, v_lens):
+        pl = self.prompt_learner
+        n_ctx = pl.n_ctx
+        mm_list, v_list = [], []
+        for mm_prompt, v_prompt in zip(mm_prompts, v_prompts):
+            # normalize=2: x/x.norm() (:204), mean over the single list element, F.normalize (:210)
+            mm_list.append(self.engine.encode_text_embedded(mm_prompt, mm_lens, pl.max_eos + n_ctx + 1, normalize=2))
+            v_list.append(self.engine.encode_text_embedded(v_prompt, v_lens, 2 + n_ctx, normalize=2))
+        assert len(mm_list) == 1
+        return mm_list[0], v_list[0]
+
+    @staticmethod
+    def _batch_images(batch, device):
+        image = batch["img"]
+        if isinstance(image, (list, tuple)):                                     # K_TRANSFORMS > 1 (:229-234)
+            image = torch.cat([im.to(device).unsqueeze(1) for im in image], dim=1).flatten(0, 1)
+        return image
+
+    @torch.no_grad()
+    def forward_prompt(self, eval_set_loader: Iterable):
+        """:214-292.  Returns (mm_classifier, visual_classifer, fusion_weight) and writes
+        mm_classifiers.pt / visual_tokens.pt into cfg.OUTPUT_DIR (rank 0 only when distributed)."""
+        e, pl, dev = self.engine, self.prompt_learner, self.device
+        C, S, D, n_ctx = len(self.tokenized_prompts), self.test_num_ins, e.spec.embed_dim, pl.n_ctx
+        dist = self._dist
+        rank, world = (dist.get_rank(), dist.get_world_size()) if dist else (0, 1)
+        f16 = dict(dtype=torch.float16, device=dev)
+        self.mm_classifier = torch.zeros((C, D), **f16)
+        self.visual_classifer = torch.zeros((C, D), **f16)
+        self.inference_text_initialized = torch.zeros(C, dtype=torch.int32, device=dev)
+        self.visual_tokens = torch.ones((C, n_ctx, D), **f16)
+        self.eval_feat4cls = torch.zeros((C, S, D), **f16)
+        text_clf = self.zero_shot_classifier if self.zero_shot_classifier is not None else torch.zeros((C, D), **f16)
+        local_labels = []
+        presharded = bool(getattr(eval_set_loader, "presharded", False))
+        for batch_idx, batch in enumerate(eval_set_loader):
+            if not presharded and batch_idx % world != rank:
+                continue
+            image = self._batch_images(batch, dev)
+            label = batch["label"].to(dev, non_blocking=True)
+            num_cls = image.shape[0] // S                                            # :237
+            exemplar_label = label.reshape(num_cls, S)[:, 0]                        # :240
+            feats = e.encode_image(image, normalize=True).reshape(num_cls, S, -1)   # :243-245
+            self.eval_feat4cls[exemplar_label] = feats                              # :247
+            mm_p, mm_l, v_p, v_l, tokens = pl(feats, exemplar_label, pl.eos_index[exemplar_label])   # :248
+            mm, v = self.get_mm_v_feats(mm_p, mm_l, v_p, v_l)                       # :249
+            self.mm_classifier[exemplar_label] = mm                                 # :251
+            self.visual_classifer[exemplar_label] = v                               # :252
+            self.inference_text_initialized[exemplar_label] = 1                     # :254
+            self.visual_tokens[exemplar_label] = tokens.half()                      # :255
+            if dist:
+                text_clf[exemplar_label] = pl.encode_zero_shot(self.tokenized_prompts[exemplar_label])
+            local_labels.append(exemplar_label)
+        local = torch.cat(local_labels) if local_labels else torch.zeros(0, dtype=torch.long, device=dev)
+
+        if dist:
+            # RCCL all-gather of the packed classifier rows: [mm | v | text | tokens]
+            from .shard import all_gather_rows
+            packed = torch.cat([self.mm_classifier[local], self.visual_classifer[local], text_clf[local],
+                                self.visual_tokens[local].flatten(1)], dim=1)
+            rows, labels = all_gather_rows(packed, local, dist)
+            self.mm_classifier[labels] = rows[:, :D]
+            self.visual_classifer[labels] = rows[:, D:2 * D]
+            text_clf[labels] = rows[:, 2 * D:3 * D]
+            self.visual_tokens[labels] = rows[:, 3 * D:].reshape(-1, n_ctx, D)
+            self.inference_text_initialized[labels] = 1
+            self.zero_shot_classifier = self.prompt_learner.zero_shot_classifier = text_clf
+        assert bool(self.inference_text_initialized.bool().all()), "a class received no exemplar batch"   # :259
+
+        # K18-K20: cross-validation argmax counts on the exemplars this rank encoded, F1, softmax(tau*F1)
+        counts = torch.zeros((3, 2, C), dtype=torch.int32, device=dev)
+        if local.numel():
+            rows = self.eval_feat4cls[local].flatten(0, 1)
+            row_labels = local.to(torch.int32).repeat_interleave(S)                # :261
+            for m, clf in enumerate((self.mm_classifier, self.visual_classifer, self.zero_shot_classifier)):   # order :272
+                e.xval_counts(rows, row_labels, clf, counts[m, 0], counts[m, 1])
+        if dist:
+            dist.all_reduce(counts)
+        n_label = torch.full((C,), S, dtype=torch.int32, device=dev)
+        self.fusion_weight = e.fusion_weights(counts, n_label, float(self.cfg.EVAL_TAU))   # :273
+        self.xval_counts = counts
+        if rank == 0 and self.cfg.OUTPUT_DIR:
+            os.makedirs(self.cfg.OUTPUT_DIR, exist_ok=True)
+            torch.save({"text_classifier": self.zero_shot_classifier.float(),      # :276-285, all fp32
+                        "vision_classifier": self.visual_classifer.float(),
+                        "mm_classifier": self.mm_classifier.float(),
+                        "fusion_weight": self.fusion_weight.float()},
+                       osp.join(self.cfg.OUTPUT_DIR, "mm_classifiers.pt"))
+            torch.save({"visual_tokens": self.visual_tokens},                       # :286-291, fp16
+                       osp.join(self.cfg.OUTPUT_DIR, "visual_tokens.pt"))
+        return self.mm_classifier, self.visual_classifer, self.fusion_weight
+
+    @torch.no_grad()
+    def forward(self, image, label=None, eval_set_loader=None, scale_no=None):
+        """:294-364, evaluation branch: [B,3,R,R] -> [B,C] fp32."""
+        if eval_set_loader is None and self.mm_classifier is None:
+            raise NotImplementedError("the training branch of CustomCLIP.forward (autograd) is out of scope; "
+                                      "pass eval_set_loader= to generate the classifiers")
+        image_features = self.engine.encode_image(image, normalize=True)           # :305-307
+        if self.mm_classifier is None:                                              # :341-342
+            self.forward_prompt(eval_set_loader)
+        mode = self.cfg.EVAL_MODE
+        if mode not in ("text", "vision", "multimodal", "fusion"):
+            raise ValueError(f"unknown EVAL_MODE {mode}")
+        return self.engine.fused_logits(image_features, self.mm_classifier, self.visual_classifer,
+                                        self.zero_shot_classifier, self.fusion_weight, mode)
+
+    __call__ = forward
+
+
+class ZeroshotCLIP:
+    """trainers/zsclip.py:32-60 (BASELINE config 1): prompts -> text features; raw logits."""
+
+    def __init__(self, clip_model: CLIPModel, tokenized_prompts: torch.Tensor, n_ctx: int = 2):
+        self.engine = e = clip_model.engine(n_ctx)
+        if not hasattr(e, "_pl_loaded"):
+            e.load_state_dict({}, {k: torch.from_numpy(v) for k, v in
+                                   synth.prompt_learner_state_dict(clip_model.spec, n_ctx, 0).items()})
+            e._pl_loaded = True
+        if not e.finalized:
+            e.finalize(256, 256, 1024)
+        self.text_features = e.encode_text_ids(tokenized_prompts, normalize=1)      # :47-49
+
+    def model_inference(self, image):
+        f = self.engine.encode_image(image, normalize=True)                         # :56-57
+        return self.engine.zeroshot_logits(f, self.text_features)                   # :58-59

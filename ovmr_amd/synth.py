@@ -173,6 +173,17 @@ def clip_state_dict(spec: ModelSpec, seed: int = 0, jitter: bool = False,
     return sd
 
 
+def prompt_learner_keys(spec: ModelSpec):
+    """Keys of PromptLearner.state_dict(): cls_token + 12 tensors per aggregator block."""
+    keys = ["cls_token"]
+    for i in range(spec.agg_layers):
+        for s in ("attn.in_proj_weight", "attn.in_proj_bias", "attn.out_proj.weight", "attn.out_proj.bias",
+                  "ln_1.weight", "ln_1.bias", "mlp.c_fc.weight", "mlp.c_fc.bias", "mlp.c_proj.weight",
+                  "mlp.c_proj.bias", "ln_2.weight", "ln_2.bias"):
+            keys.append(f"aggregator.resblocks.{i}.{s}")
+    return keys
+
+
 def prompt_learner_state_dict(spec: ModelSpec, n_ctx: int = 2, seed: int = 0,
                               jitter: bool = False) -> Dict[str, np.ndarray]:
     """The 1 + 12*agg_layers trainable tensors of PromptLearner.state_dict()."""

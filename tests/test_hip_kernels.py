@@ -1,0 +1,166 @@
+"""Unit parity of each HIP kernel (through the C ABI's ovmr_debug_* hooks) against a plain torch
+fp32/fp64 statement of the same op.  Needs an MI355X: run with `pytest -m gpu`."""
+import ctypes
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+EPI_NONE, EPI_BIAS, EPI_BIAS_QGELU, EPI_BIAS_RES, EPI_PATCH, EPI_SCALE = range(6)
+GEMM_VARIANTS = [0, 1]
+ATTN_VARIANTS = [0, 1]
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from ovmr_amd import runtime
+    assert torch.cuda.is_available(), "GPU tests need a ROCm device"
+    return runtime.load_library()
+
+
+def _p(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _s():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _h(x):  # round through fp16 like the reference's fp16 tensors
+    return x.half().float()
+
+
+def _ref_gemm_f16(A, W, bias, res, pos, epi, scale, rows_in, rows_out):
+    acc = A.double() @ W.double().t()
+    if epi == EPI_NONE:
+        return _h(acc.float())
+    if epi == EPI_BIAS:
+        return _h((acc + bias.double()).float())
+    if epi == EPI_BIAS_QGELU:
+        u = _h((acc + bias.double()).float())
+        return _h(u * _h(torch.sigmoid(_h(1.702 * u))))
+    if epi == EPI_BIAS_RES:
+        return _h(_h((acc + bias.double()).float()) + res.float())
+    if epi == EPI_SCALE:
+        return _h(_h(acc.float()) * scale)
+    if epi == EPI_PATCH:
+        M, N = acc.shape
+        B = M // rows_in
+        out = torch.zeros(B * rows_out, N)
+        v = _h(_h(acc.float()).reshape(B, rows_in, N) + pos.float()[1:1 + rows_in])
+        out.reshape(B, rows_out, N)[:, 1:] = v
+        return out
+    raise AssertionError
+
+
+@pytest.mark.parametrize("variant", GEMM_VARIANTS)
+@pytest.mark.parametrize("M,N,K,epi", [
+    (256, 256, 256, EPI_BIAS), (197 * 3, 768, 768, EPI_BIAS_RES), (1000, 3072, 768, EPI_BIAS_QGELU),
+    (130, 2304, 768, EPI_BIAS), (5, 128, 128, EPI_NONE), (64, 1000, 512, EPI_SCALE), (37, 6, 128, EPI_SCALE),
+    (4 * 196, 768, 768, EPI_PATCH), (300, 768, 3072, EPI_BIAS_RES), (1, 512, 768, EPI_NONE),
+    (2048, 512, 2048, EPI_BIAS_RES), (513, 1536, 512, EPI_BIAS),
+])
+def test_gemm_f16(lib, variant, M, N, K, epi):
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K + epi)
+    A = (torch.randn(M, K, generator=g) * 0.5).half()
+    W = (torch.randn(N, K, generator=g) * K ** -0.5).half()
+    bias = (torch.randn(N, generator=g) * 0.1).half()
+    rows_in, rows_out = (196, 197) if epi == EPI_PATCH else (0, 0)
+    out_rows = M // rows_in * rows_out if epi == EPI_PATCH else M
+    res = (torch.randn(out_rows, N, generator=g)).half()
+    pos = (torch.randn(197, N, generator=g) * 0.1).half()
+    scale = 100.0
+    ref = _ref_gemm_f16(A, W, bias, res, pos, epi, scale, rows_in, rows_out)
+    d = "cuda"
+    Ad, Wd, bd, pd = A.to(d), W.to(d), bias.to(d), pos.to(d)
+    C = res.clone().to(d) if epi == EPI_BIAS_RES else torch.zeros(out_rows, N, dtype=torch.float16, device=d)
+    rc = lib.ovmr_debug_gemm(0, variant, _p(Ad), _p(Wd), _p(bd), _p(C) if epi == EPI_BIAS_RES else None, _p(pd), _p(C),
+                             M, N, K, N, epi, scale, rows_in, rows_out, _s())
+    assert rc == 0
+    torch.cuda.synchronize()
+    got = C.float().cpu()
+    if epi == EPI_PATCH:
+        keep = torch.ones(out_rows, dtype=torch.bool)
+        keep[::rows_out] = False        # CLS rows are written by a separate kernel
+        got, ref = got[keep], ref[keep]
+    # fp32 accumulation order differs from fp64: allow one fp16 ulp of the largest magnitude involved
+    tol = 2e-3 * max(1.0, float(ref.abs().max()))
+    assert torch.isfinite(got).all()
+    assert float((got - ref).abs().max()) <= tol, f"max err {(got - ref).abs().max()}"
+    assert float(((got - ref).abs() > tol / 8).float().mean()) < 0.02
+
+
+@pytest.mark.parametrize("M,N,K,epi", [(36, 384, 128, EPI_BIAS), (288, 1536, 512, EPI_BIAS), (288, 512, 2048, EPI_BIAS_RES),
+                                       (1000, 2048, 512, EPI_BIAS_QGELU), (7, 128, 512, EPI_BIAS_RES)])
+def test_gemm_f32(lib, M, N, K, epi):
+    g = torch.Generator().manual_seed(M + N + K)
+    A, W = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) * K ** -0.5
+    bias, res = torch.randn(N, generator=g) * 0.1, torch.randn(M, N, generator=g)
+    acc = (A.double() @ W.double().t() + bias.double())
+    ref = {EPI_BIAS: acc, EPI_BIAS_RES: acc + res.double(), EPI_BIAS_QGELU: acc * torch.sigmoid(1.702 * acc)}[epi].float()
+    d = "cuda"
+    C = res.clone().to(d) if epi == EPI_BIAS_RES else torch.zeros(M, N, device=d)
+    Ad, Wd, bd = A.to(d), W.to(d), bias.to(d)
+    rc = lib.ovmr_debug_gemm(1, 0, _p(Ad), _p(Wd), _p(bd), _p(C) if epi == EPI_BIAS_RES else None, None, _p(C),
+                             M, N, K, N, epi, 1.0, 0, 0, _s())
+    assert rc == 0
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(C.cpu().numpy(), ref.numpy(), atol=2e-4, rtol=2e-4)
+
+
+@pytest.mark.parametrize("rows,D,f32", [(1000, 768, 0), (77 * 3, 512, 0), (5, 128, 0), (36, 512, 1), (9, 1024, 0), (3, 2048, 0)])
+def test_layernorm(lib, rows, D, f32):
+    g = torch.Generator().manual_seed(rows + D)
+    x = torch.randn(rows, D, generator=g) * 3 + 0.5
+    gam, bet = torch.randn(D, generator=g) * 0.1 + 1, torch.randn(D, generator=g) * 0.1
+    xin = x if f32 else x.half()
+    ref = torch.nn.functional.layer_norm(xin.float(), (D,), gam, bet, 1e-5)
+    ref = ref if f32 else _h(ref)
+    xd = xin.cuda()
+    y = torch.empty_like(xd)
+    gd, bd = gam.cuda(), bet.cuda()
+    assert lib.ovmr_debug_layernorm(f32, _p(xd), _p(y), _p(gd), _p(bd), rows, D, D, _s()) == 0
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(y.float().cpu().numpy(), ref.numpy(), atol=1e-5 if f32 else 4e-3, rtol=1e-5 if f32 else 2e-3)
+
+
+def _ref_attention(qkv, B, L, H, causal):
+    D = H * 64
+    q, k, v = qkv.double().reshape(B, L, 3, H, 64).permute(2, 0, 3, 1, 4)
+    s = q @ k.transpose(-1, -2) * 0.125
+    if causal:
+        s = s + torch.full((L, L), float("-inf"), dtype=torch.float64).triu_(1)
+    return (s.softmax(-1) @ v).permute(0, 2, 1, 3).reshape(B * L, D).float()
+
+
+@pytest.mark.parametrize("variant", ATTN_VARIANTS)
+@pytest.mark.parametrize("B,L,H,causal", [(3, 197, 12, 0), (2, 5, 2, 0), (4, 77, 8, 1), (5, 9, 2, 1), (1, 577, 16, 0),
+                                          (2, 64, 4, 0), (2, 65, 4, 1), (3, 6, 8, 1)])
+def test_attention_f16(lib, variant, B, L, H, causal):
+    g = torch.Generator().manual_seed(B * L + H)
+    qkv = (torch.randn(B * L, 3 * H * 64, generator=g)).half()
+    # spike one key so the online-softmax rescale path is exercised (cdna guide rule 26)
+    qkv[L // 2, H * 64:H * 64 + 64] *= 6.0
+    ref = _ref_attention(qkv.float(), B, L, H, causal)
+    qd = qkv.cuda()
+    out = torch.zeros(B * L, H * 64, dtype=torch.float16, device="cuda")
+    assert lib.ovmr_debug_attention(0, variant, _p(qd), _p(out), B, L, H, causal, _s()) == 0
+    torch.cuda.synchronize()
+    got = out.float().cpu()
+    assert torch.isfinite(got).all()
+    assert float((got - ref).abs().max()) < 6e-3, f"max err {(got - ref).abs().max()}"
+
+
+@pytest.mark.parametrize("B,L,H", [(6, 18, 8), (3, 6, 2), (2, 66, 8), (1, 10, 12)])
+def test_attention_f32(lib, B, L, H):
+    g = torch.Generator().manual_seed(B + L + H)
+    qkv = torch.randn(B * L, 3 * H * 64, generator=g)
+    ref = _ref_attention(qkv, B, L, H, 0)
+    qd = qkv.cuda()
+    out = torch.zeros(B * L, H * 64, device="cuda")
+    assert lib.ovmr_debug_attention(1, 0, _p(qd), _p(out), B, L, H, 0, _s()) == 0
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), atol=2e-5, rtol=1e-4)

@@ -1,0 +1,276 @@
+"""End-to-end parity of the HIP path (through ovmr_amd's module mirror -> C ABI) against
+ (a) the golden vectors recorded from the real reference (tests/golden/*.npz) and
+ (b) the CPU oracle on freshly seeded inputs, incl. ragged / edge cases.
+Bar (BASELINE.json north_star): 1 - cosine <= 1e-3 for classifier rows, features and per-image
+outputs in fp16.  Needs an MI355X: `pytest -m gpu`."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import COS_TOL, assert_cosine, cosine_rows
+from ovmr_amd import synth
+
+pytestmark = pytest.mark.gpu
+SEED = 11
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import ovmr_oracle
+    return ovmr_oracle
+
+
+_MODELS = {}
+
+
+def _clip(name, n_ctx=2):
+    """One CLIPModel (+ engine with prompt-learner weights) per (spec, n_ctx), shared by the tests."""
+    from ovmr_amd import modules
+    key = (name, n_ctx)
+    if key not in _MODELS:
+        spec = synth.SPECS[name]
+        sd = {k: torch.from_numpy(v) for k, v in synth.clip_state_dict(spec, SEED, jitter=True).items()}
+        cm = modules.CLIPModel(sd, spec)
+        e = cm.engine(n_ctx)
+        e.load_state_dict({}, {k: torch.from_numpy(v) for k, v in
+                               synth.prompt_learner_state_dict(spec, n_ctx, SEED, True).items()})
+        e._pl_loaded = True
+        e.finalize(64, 64, 256)
+        _MODELS[key] = cm
+    return _MODELS[key]
+
+
+def _oracle_sd(O, name):
+    return O.convert_weights(O.to_torch(synth.clip_state_dict(synth.SPECS[name], SEED, jitter=True)), "fp16")
+
+
+@pytest.mark.parametrize("name,key,n_img", [("tiny", "tiny", 4), ("small", "small", 3), ("ViT-B/16", "vitb16", 8)])
+def test_encode_image_vs_golden(golden, name, key, n_img):
+    g = golden(key)
+    e = _clip(name).engine(2)
+    img = synth.images(n_img, synth.SPECS[name].image_resolution, seed=1234)
+    for dtype in (torch.float32, torch.float16):           # fp32 input is cast on device like image.type(fp16)
+        f = e.encode_image(torch.from_numpy(img).to(dtype), normalize=False).float().cpu().numpy()
+        assert_cosine(f, g["l1_fp16_image_features"], COS_TOL, "image features vs reference fp16 path")
+        assert_cosine(f, g["l1_fp32_image_features"], COS_TOL, "image features vs reference fp32 path")
+
+
+@pytest.mark.parametrize("name,key", [("tiny", "tiny"), ("small", "small"), ("ViT-B/16", "vitb16")])
+def test_encode_text_ids_and_zeroshot_vs_golden(golden, name, key):
+    g = golden(key)
+    cm = _clip(name)
+    e = cm.engine(2)
+    ids = torch.from_numpy(synth.class_token_ids(6, seed=4321))
+    t = e.encode_text_ids(ids, normalize=0)
+    assert_cosine(t.float().cpu().numpy(), g["l1_fp16_text_features"], COS_TOL, "text features")
+    t_short = e.encode_text_ids(ids, seq_len=int(ids.argmax(-1).max()) + 1, normalize=0)      # causal truncation is exact
+    assert_cosine(t_short.float().cpu().numpy(), t.float().cpu().numpy(), 1e-6, "truncated text")
+    # zsclip raw logits (trainers/zsclip.py:55-60)
+    from ovmr_amd.modules import ZeroshotCLIP
+    n_img = g["l1_fp16_image_features"].shape[0]
+    zs = ZeroshotCLIP(cm, ids)
+    img = torch.from_numpy(synth.images(n_img, synth.SPECS[name].image_resolution, seed=1234))
+    lg = zs.model_inference(img).float().cpu().numpy()
+    assert_cosine(lg, g["l1_fp16_zs_logits"], COS_TOL, "zero-shot logits")
+    np.testing.assert_allclose(lg, g["l1_fp16_zs_logits"], atol=0.3)
+
+
+@pytest.mark.parametrize("name,key,tag,n_ctx", [("tiny", "tiny", "l2", 2), ("tiny", "tiny", "l2n1", 1),
+                                                ("small", "small", "l2", 2), ("ViT-B/16", "vitb16", "l2", 2)])
+def test_prompt_learner_and_text_encoder_vs_golden(golden, name, key, tag, n_ctx):
+    from ovmr_amd import modules
+    g = golden(key)
+    cm = _clip(name, n_ctx)
+    cfg = modules.make_cfg(n_ctx=n_ctx, num_shots=int(g["meta_shots"]), output_dir="")
+    pl_sd = {k: torch.from_numpy(v) for k, v in synth.prompt_learner_state_dict(synth.SPECS[name], n_ctx, SEED, True).items()}
+    pl = modules.PromptLearner(cfg, torch.from_numpy(g[f"{tag}_tokenized_prompts"]), cm, state_dict=pl_sd, reserve=(64, 64, 256))
+    assert sorted(pl.state_dict().keys()) == [str(k) for k in g[f"{tag}_state_dict_keys"]]
+    np.testing.assert_array_equal(pl.prompt_tokens.float().cpu().numpy(), g[f"{tag}_prompt_tokens"].astype(np.float32))
+    assert_cosine(pl.zero_shot_classifier.float().cpu().numpy(), g[f"{tag}_zero_shot_classifier"], COS_TOL, "zero-shot clf")
+    feats = torch.from_numpy(g[f"{tag}_pl_feats"]).half().cuda()
+    label = torch.from_numpy(g[f"{tag}_pl_label"]).cuda()
+    eos = torch.from_numpy(g[f"{tag}_pl_eos"]).cuda()
+    mm_p, mm_l, v_p, v_l, tokens = pl(feats, label, eos)
+    assert isinstance(mm_p, list) and len(mm_p) == 1 and tokens.dtype == torch.float32
+    np.testing.assert_array_equal(mm_l.cpu().numpy(), g[f"{tag}_pl_mm_lens"])
+    np.testing.assert_array_equal(v_l.cpu().numpy(), g[f"{tag}_pl_v_lens"])
+    assert v_l.dtype == torch.int32
+    np.testing.assert_allclose(tokens.cpu().numpy(), g[f"{tag}_pl_tokens"], atol=5e-4, rtol=1e-3)   # fp32 aggregator
+    assert_cosine(mm_p[0].float().cpu().numpy(), g[f"{tag}_pl_mm_prompts"].astype(np.float32), 1e-5, "mm prompts")
+    assert_cosine(v_p[0].float().cpu().numpy(), g[f"{tag}_pl_v_prompts"].astype(np.float32), 1e-5, "v prompts")
+    # TextEncoder.forward on the REFERENCE's prompts
+    te = modules.TextEncoder(cm, n_ctx)
+    out_mm = te(torch.from_numpy(g[f"{tag}_pl_mm_prompts"]).cuda(), torch.from_numpy(g[f"{tag}_pl_mm_lens"]).cuda())
+    out_v = te(torch.from_numpy(g[f"{tag}_pl_v_prompts"]).cuda(), torch.from_numpy(g[f"{tag}_pl_v_lens"]).cuda())
+    assert_cosine(out_mm.float().cpu().numpy(), g[f"{tag}_te_mm"], COS_TOL, "TextEncoder(mm)")
+    assert_cosine(out_v.float().cpu().numpy(), g[f"{tag}_te_v"], COS_TOL, "TextEncoder(v)")
+
+
+def _margin_ok_rows(logits, margin):
+    top2 = np.sort(logits, axis=1)[:, -2:]
+    return (top2[:, 1] - top2[:, 0]) > margin
+
+
+@pytest.mark.parametrize("name,key,tag,n_ctx", [("tiny", "tiny", "l2", 2), ("tiny", "tiny", "l2n1", 1),
+                                                ("small", "small", "l2", 2), ("ViT-B/16", "vitb16", "l2", 2)])
+def test_generate_classifier_vs_golden(golden, tmp_path, O, name, key, tag, n_ctx):
+    """generate_classifier.sh path: forward_prompt -> mm_classifiers.pt / visual_tokens.pt -> four EVAL_MODEs."""
+    from ovmr_amd import modules
+    g = golden(key)
+    spec = synth.SPECS[name]
+    S, cpb = int(g["meta_shots"]), int(g["meta_classes_per_batch"])
+    cm = _clip(name, n_ctx)
+    cfg = modules.make_cfg(n_ctx=n_ctx, num_shots=S, eval_tau=float(g["meta_tau"]), output_dir=str(tmp_path))
+    pl_sd = {k: torch.from_numpy(v) for k, v in synth.prompt_learner_state_dict(spec, n_ctx, SEED, True).items()}
+    model = modules.CustomCLIP(cfg, torch.from_numpy(g[f"{tag}_tokenized_prompts"]), cm, prompt_learner_state=pl_sd,
+                               reserve=(64, 64, 256))
+    labels = g[f"{tag}_eval_labels"]
+    img = synth.images(len(labels), spec.image_resolution, seed=1234, class_ids=labels, class_strength=0.6)
+    step = cpb * S
+    loader = [{"img": torch.from_numpy(img[s:s + step]), "label": torch.from_numpy(labels[s:s + step])}
+              for s in range(0, len(labels), step)]
+    qlab = g[f"{tag}_query_labels"]
+    q = torch.from_numpy(synth.images(len(qlab), spec.image_resolution, seed=777, class_ids=qlab, class_strength=0.6))
+    outs = {}
+    for mode in ("fusion", "text", "vision", "multimodal"):
+        cfg.EVAL_MODE = mode
+        outs[mode] = model(q, eval_set_loader=loader)
+        assert outs[mode].dtype == torch.float32 and outs[mode].shape == (len(qlab), 6)
+
+    saved = torch.load(os.path.join(str(tmp_path), "mm_classifiers.pt"), map_location="cpu")
+    assert sorted(saved) == ["fusion_weight", "mm_classifier", "text_classifier", "vision_classifier"]
+    assert all(v.dtype == torch.float32 for v in saved.values())
+    vt = torch.load(os.path.join(str(tmp_path), "visual_tokens.pt"), map_location="cpu")["visual_tokens"]
+    assert vt.dtype == torch.float16 and tuple(vt.shape) == (6, n_ctx, spec.embed_dim)
+    for k in ("text_classifier", "vision_classifier", "mm_classifier"):
+        assert_cosine(saved[k].numpy(), g[f"{tag}_saved_{k}"], COS_TOL, k)
+    assert_cosine(vt.float().numpy(), g[f"{tag}_saved_visual_tokens"], COS_TOL, "visual_tokens")
+    assert_cosine(model.eval_feat4cls.float().cpu().numpy(), g[f"{tag}_eval_feat4cls"], COS_TOL, "eval_feat4cls")
+
+    # fusion weights: exact F1 arithmetic, but an argmax between near-tied fp16 logits may flip.  Compare
+    # where the reference's own margins are clear, and always compare against our own counts.
+    ls = float(np.exp(np.log(100.0)))
+    ref_f = torch.from_numpy(g[f"{tag}_eval_feat4cls"]).half()
+    clear = np.ones(6 * S, dtype=bool)
+    for k in ("mm_classifier", "vision_classifier", "text_classifier"):
+        lg = O.cross_validation_logits(ref_f, torch.from_numpy(g[f"{tag}_saved_{k}"]).half(), torch.tensor(ls)).float().numpy()
+        clear &= _margin_ok_rows(lg, 0.26)
+    if clear.all():
+        np.testing.assert_allclose(saved["fusion_weight"].numpy(), g[f"{tag}_saved_fusion_weight"], atol=1e-5)
+    counts = model.xval_counts.cpu()
+    fw_from_counts = torch.stack([O.f1_from_counts(counts[m, 0], counts[m, 1], torch.full((6,), S)) for m in range(3)], -1)
+    np.testing.assert_allclose(saved["fusion_weight"].numpy(), (float(g["meta_tau"]) * fw_from_counts).softmax(-1).numpy(), atol=1e-6)
+    assert int(counts[:, 1].sum()) == 3 * 6 * S
+
+    # per-image outputs: cosine bar on the probability rows
+    for mode in ("text", "vision", "multimodal"):
+        assert_cosine(outs[mode].cpu().numpy(), g[f"{tag}_logits_{mode}"], 5 * COS_TOL if name == "tiny" else COS_TOL, mode)
+    if clear.all():
+        assert_cosine(outs["fusion"].cpu().numpy(), g[f"{tag}_logits_fusion"], 5 * COS_TOL if name == "tiny" else COS_TOL, "fusion")
+
+
+def test_fusion_head_vs_oracle(O):
+    """K18-K21 in isolation on separable synthetic features: counts, F1 -> fusion weights and the four
+    EVAL_MODE outputs must match the oracle given IDENTICAL fp16 inputs."""
+    e = _clip("tiny").engine(2)
+    D = 128
+    for C, S, B in ((6, 4, 5), (37, 3, 9), (1000, 4, 33), (130, 16, 256)):
+        g = torch.Generator().manual_seed(C * 31 + S)
+        centers = torch.nn.functional.normalize(torch.randn(C, D, generator=g), dim=-1)
+        feats = torch.nn.functional.normalize(centers[:, None] + 0.35 * torch.randn(C, S, D, generator=g), dim=-1).half()
+        clfs = [torch.nn.functional.normalize(centers + s * torch.randn(C, D, generator=g), dim=-1).half()
+                for s in (0.15, 0.3, 0.6)]
+        clfs[2][C // 2] = clfs[2][C // 3]      # a duplicated class row: exact ties, first index must win
+        ls = torch.tensor(float(e.logit_scale))
+        fw_ref, f1_ref = O.fusion_weights(feats, clfs[0], clfs[1], clfs[2], ls, 10.0)
+        counts = torch.zeros((3, 2, C), dtype=torch.int32, device="cuda")
+        rows = feats.flatten(0, 1).cuda()
+        lab = torch.arange(C, dtype=torch.int32).repeat_interleave(S).cuda()
+        for m in range(3):
+            e.xval_counts(rows, lab, clfs[m], counts[m, 0], counts[m, 1])
+        fw = e.fusion_weights(counts, torch.full((C,), S, dtype=torch.int32), 10.0).cpu()
+        # rows whose top-2 margin in the oracle exceeds one fp16 logit step must agree exactly
+        flips = 0
+        for m in range(3):
+            lg = O.cross_validation_logits(feats, clfs[m], ls).float().numpy()
+            flips += int((~_margin_ok_rows(lg, 0.13)).sum())
+        bad = (fw - fw_ref).abs().max(dim=1).values > 1e-5
+        assert int(bad.sum()) <= 2 * flips, f"C={C}: {int(bad.sum())} classes differ, {flips} near-tie rows"
+        q = torch.nn.functional.normalize(centers[torch.arange(B) % C] + 0.3 * torch.randn(B, D, generator=g), dim=-1).half()
+        for mode in ("fusion", "text", "vision", "multimodal"):
+            ref = O.inference_logits(q, clfs[0], clfs[1], clfs[2], fw_ref, ls, mode)
+            got = e.fused_logits(q, clfs[0], clfs[1], clfs[2], fw_ref, mode).cpu()
+            assert got.shape == (B, C) and got.dtype == torch.float32
+            assert_cosine(got.numpy(), ref.numpy(), 2e-4, f"{mode} C={C}")
+            frac_bad = float(((got - ref).abs() > 2e-3 + 0.07 * ref.abs()).float().mean())
+            assert frac_bad < 0.01, f"{mode}: {frac_bad:.3%} of probabilities off by more than one fp16 logit step"
+
+
+def test_never_predicted_class_gets_uniform_weight():
+    """G7: tp = n_pred = 0 -> precision NaN -> f1 0 -> softmax(0,0,0) = 1/3 each."""
+    e = _clip("tiny").engine(2)
+    counts = torch.zeros((3, 2, 4), dtype=torch.int32)
+    counts[0, :, 1] = torch.tensor([2, 3])           # class 1, mm: tp 2, n_pred 3 -> p 2/3, r 2/4
+    fw = e.fusion_weights(counts, torch.full((4,), 4, dtype=torch.int32), 10.0).cpu().numpy()
+    np.testing.assert_allclose(fw[0], [1 / 3] * 3, atol=1e-6)
+    f1 = 2 * (2 / 3) * 0.5 / (2 / 3 + 0.5)
+    ref = np.exp([10 * f1, 0, 0]) / np.exp([10 * f1, 0, 0]).sum()
+    np.testing.assert_allclose(fw[1], ref, atol=1e-6)
+
+
+@pytest.mark.parametrize("B", [1, 2, 63, 64, 65, 130])
+def test_encode_image_batch_edges_vs_oracle(O, B):
+    """Ragged batches (M = B*L not a tile multiple) and chunking past the reserved batch (64)."""
+    spec = synth.SPECS["small"]
+    e = _clip("small").engine(2)
+    img = torch.from_numpy(synth.images(B, spec.image_resolution, seed=99))
+    got = e.encode_image(img, normalize=True).float().cpu()
+    assert got.shape == (B, spec.embed_dim) and torch.isfinite(got).all()
+    idx = sorted(set([0, B // 2, B - 1]))
+    with torch.no_grad():
+        ref = O.l2_normalize(O.encode_image(img[idx].half(), _oracle_sd(O, "small"))).float()
+    assert_cosine(got[idx].numpy(), ref.numpy(), COS_TOL, f"B={B}")
+    np.testing.assert_allclose(got.norm(dim=-1).numpy(), 1.0, atol=2e-3)
+
+
+def test_empty_inputs():
+    e = _clip("tiny").engine(2)
+    spec = synth.SPECS["tiny"]
+    assert e.encode_image(torch.zeros(0, 3, 32, 32)).shape == (0, spec.embed_dim)
+    assert e.encode_text_ids(torch.zeros(0, 77, dtype=torch.long)).shape == (0, spec.embed_dim)
+    assert e.generate_tokens(torch.zeros(0, 4, spec.embed_dim, dtype=torch.float16)).shape == (0, 2, spec.embed_dim)
+
+
+def test_missing_weight_fails_loudly():
+    from ovmr_amd.runtime import Engine, OvmrError
+    e = Engine(synth.SPECS["tiny"], 2)
+    e.set_weight("logit_scale", torch.tensor(4.6))
+    with pytest.raises(OvmrError, match="never set"):
+        e.finalize(8, 8, 8)
+    with pytest.raises(OvmrError, match="unknown weight name"):
+        e.set_weight("visual.bogus", torch.zeros(3))
+    with pytest.raises(OvmrError, match="finalize"):
+        e.encode_image(torch.zeros(1, 3, 32, 32))
+
+
+def test_full_size_properties():
+    """ViT-B/16 at the benchmark batch (256): size-independent properties -- batch invariance (an image's
+    feature does not depend on its batch mates or position), unit norm, determinism."""
+    spec = synth.SPECS["ViT-B/16"]
+    cm = _clip("ViT-B/16")
+    e = cm.engine(2)
+    e.finalize(256, 256, 1024)
+    g = torch.Generator(device="cuda").manual_seed(5)
+    img = torch.randn(256, 3, 224, 224, generator=g, device="cuda", dtype=torch.float16)
+    f1 = e.encode_image(img, normalize=True)
+    f2 = e.encode_image(img, normalize=True)
+    assert torch.equal(f1, f2), "non-deterministic"
+    perm = torch.randperm(256, device="cuda")
+    f3 = e.encode_image(img[perm], normalize=True)
+    assert_cosine(f3.float().cpu().numpy(), f1[perm].float().cpu().numpy(), 1e-6, "batch permutation")
+    f4 = e.encode_image(img[:7], normalize=True)
+    assert_cosine(f4.float().cpu().numpy(), f1[:7].float().cpu().numpy(), 1e-6, "sub-batch")
+    np.testing.assert_allclose(f1.float().norm(dim=-1).cpu().numpy(), 1.0, atol=2e-3)
+    e.finalize(64, 64, 256)
