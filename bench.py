@@ -1,0 +1,318 @@
+#!/usr/bin/env python3
+"""Benchmark of the OVMR hot path on MI355X: images/sec for ViT-B/16 encode + fusion at
+1 000 classes x 16 shots (BASELINE.json `metric`), 1/2/4/8 GPUs of one node.
+
+One STEP = one whole classifier-generation job plus fusion-mode inference, nothing cached:
+  generation  16 000 exemplar images (1000 classes x 16 shots) -> image encoder -> visual-token
+              generator -> multimodal / vision prompts -> text encoder (mm, vision, zero-shot text
+              classifiers) -> cross-validation argmax counts -> F1 -> fusion weights;
+  inference   --queries images in batches of 256 -> image encoder -> three classifier GEMMs ->
+              softmax -> fused probabilities.
+value = (exemplar + query images of ALL ranks) / wall time of a step, inputs resident in HBM.
+With N > 1 (launched by torch.distributed.run, one process per GPU, backend nccl = RCCL) the classes
+and the queries are sharded over ranks (strong scaling of the named 1k-class job); the only data-path
+collectives are one all-gather of classifier rows and one all-reduce of the F1 counters.
+
+The JSON line also carries
+  roofline      the dominant kernel (fp16 MFMA GEMM, c_fc shape 50432x3072x768) timed live with HIP events
+                on the stream it is launched on, against the 2.5 PFLOP/s dense fp16 MFMA peak;
+  cpu_baseline  the CPU oracle (a torch-CPU port of the reference path, validated against golden vectors of
+                the real reference) timed on this host's cores on a bounded sample (rank 0, N = 1 only).
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--model", default="ViT-B/16")
+    ap.add_argument("--classes", type=int, default=1000)
+    ap.add_argument("--shots", type=int, default=16)
+    ap.add_argument("--queries", type=int, default=4096)
+    ap.add_argument("--batch", type=int, default=256, help="images per encoder launch sequence (TEST.BATCH_SIZE)")
+    ap.add_argument("--classes-per-batch", type=int, default=64)
+    ap.add_argument("--gemm", type=int, default=int(os.environ.get("OVMR_GEMM", "0")))
+    ap.add_argument("--attn", type=int, default=int(os.environ.get("OVMR_ATTN", "0")))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-classes", type=int, default=2)
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # launched by hand with --gpus N: start one process per GPU as a child, before touching the GPU
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", "29511", os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from ovmr_amd import modules, synth
+    from ovmr_amd.data import ResidentEvalSet
+    from ovmr_amd.shard import shard_range
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dev = torch.device(f"cuda:{local}")
+    torch.cuda.set_device(dev)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    spec = synth.SPECS[args.model]
+    C, S, Q, n_ctx = args.classes, args.shots, args.queries, 2
+    R = spec.image_resolution
+
+    # ---- synthetic CLIP-init weights, generated on the device: same shapes/std as
+    # ovmr_amd.synth, no biases/affine jitter, logit_scale = ln 100
+    gen = torch.Generator(device=dev).manual_seed(1234)
+    sd = device_clip_state(spec, gen, dev)
+    pl = device_pl_state(spec, n_ctx, gen, dev)
+    cm = modules.CLIPModel(sd, spec, str(dev))
+    cfg = modules.make_cfg(n_ctx=n_ctx, num_shots=S, eval_mode="fusion", eval_tau=10.0, output_dir="",
+                           test_batch_size=args.batch)
+    tok = torch.from_numpy(synth.class_token_ids(C, seed=4321))
+    model = modules.CustomCLIP(cfg, tok, cm, prompt_learner_state=pl,
+                               reserve=(args.batch, max(256, min(C, 2048)), max(C, 1024)))
+    eng = model.engine
+    eng.set_option("gemm", args.gemm)
+    eng.set_option("attn", args.attn)
+
+    # ---- this rank's shard of the job, resident in HBM (N(0,1) images, fp16), seed 1234 + rank
+    c0, c1 = shard_range(C, rank, world)
+    q0, q1 = shard_range(Q, rank, world)
+    ig = torch.Generator(device=dev).manual_seed(1234 + rank)
+    ex_img = torch.empty(((c1 - c0) * S, 3, R, R), dtype=torch.float16, device=dev)
+    for s in range(0, ex_img.shape[0], 1024):
+        ex_img[s:s + 1024] = torch.randn((min(1024, ex_img.shape[0] - s), 3, R, R), generator=ig, device=dev).half()
+    q_img = torch.randn((q1 - q0, 3, R, R), generator=ig, device=dev).half()
+    loader = ResidentEvalSet(ex_img, torch.arange(c0, c1, device=dev), S, args.classes_per_batch, presharded=True)
+
+    def step():
+        if world == 1:
+            model.zero_shot_classifier = model.prompt_learner.zero_shot_classifier = \
+                model.prompt_learner.encode_zero_shot(model.tokenized_prompts)     # part of the job (:118-126)
+        model.forward_prompt(loader)
+        outs = None
+        for b in range(0, q_img.shape[0], args.batch):
+            outs = model(q_img[b:b + args.batch])
+        return outs
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+    assert out is None or bool(torch.isfinite(out).all())
+
+    # phase split (untimed extra pass, informational)
+    barrier()
+    tg = time.perf_counter(); model.forward_prompt(loader); torch.cuda.synchronize(); tg = time.perf_counter() - tg
+    ti = time.perf_counter()
+    for b in range(0, q_img.shape[0], args.batch):
+        model(q_img[b:b + args.batch])
+    torch.cuda.synchronize(); ti = time.perf_counter() - ti
+
+    images_per_step = C * S + Q
+    value = images_per_step * args.steps / dt
+    roof = measure_roofline(eng, spec, args, dev) if rank == 0 else None
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(spec, sd, pl, tok, args, n_ctx)
+
+    if rank == 0:
+        flops_img = eng.flops_per_image()
+        line = {
+            "metric": "images/sec ViT-B/16 encode+fusion, 1k-class×16-shot, 1/2/4/8 MI355X",
+            "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1000 * dt / args.steps, 3), "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+            "config": {"workload": f"OVMR classifier generation + fusion inference, {args.model}, {C} classes x {S} shots "
+                                   f"({C * S} exemplar images) + {Q} query images, batch {args.batch}, n_ctx 2, tau 10",
+                       "parallelism": f"class/query sharding over {world} rank(s); all-gather rows + all-reduce counters",
+                       "gemm_variant": args.gemm, "attn_variant": args.attn,
+                       "images_per_step": images_per_step},
+            "roofline": roof,
+            "cpu_baseline": cpu,
+            "phases": {"generation_images_per_s_rank0": round((c1 - c0) * S / tg, 1),
+                       "inference_images_per_s_rank0": round((q1 - q0) / ti, 1) if q1 > q0 else None,
+                       "encoder_tflops_e2e": round(value * flops_img / 1e12, 1),
+                       "e2e_frac_of_fp16_mfma_peak": round(value * flops_img / 1e12 / (2500.0 * world), 4)},
+        }
+        if cpu and cpu.get("value"):
+            line["gpu_over_cpu"] = round(value / cpu["value"], 1)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+# ------------------------------------------------------------------------------------------
+def device_clip_state(spec, gen, dev):
+    import math
+    import torch
+
+    def n(shape, std):
+        return torch.randn(shape, generator=gen, device=dev) * std
+
+    sd = {}
+    W, P, L, T, E = spec.vision_width, spec.vision_patch_size, spec.vision_tokens, spec.transformer_width, spec.embed_dim
+    sd["visual.class_embedding"] = n((W,), W ** -0.5)
+    sd["visual.positional_embedding"] = n((L, W), W ** -0.5)
+    sd["visual.proj"] = n((W, E), W ** -0.5)
+    sd["visual.conv1.weight"] = n((W, 3, P, P), (3 * P * P) ** -0.5)
+    for nm in ("visual.ln_pre", "visual.ln_post"):
+        sd[nm + ".weight"] = torch.ones(W, device=dev)
+        sd[nm + ".bias"] = torch.zeros(W, device=dev)
+
+    def blocks(prefix, width, layers):
+        a, p, f = width ** -0.5, (width ** -0.5) * ((2 * layers) ** -0.5), (2 * width) ** -0.5
+        for i in range(layers):
+            q = f"{prefix}{i}."
+            sd[q + "attn.in_proj_weight"] = n((3 * width, width), a)
+            sd[q + "attn.in_proj_bias"] = torch.zeros(3 * width, device=dev)
+            sd[q + "attn.out_proj.weight"] = n((width, width), p)
+            sd[q + "attn.out_proj.bias"] = torch.zeros(width, device=dev)
+            sd[q + "mlp.c_fc.weight"] = n((4 * width, width), f)
+            sd[q + "mlp.c_fc.bias"] = torch.zeros(4 * width, device=dev)
+            sd[q + "mlp.c_proj.weight"] = n((width, 4 * width), p)
+            sd[q + "mlp.c_proj.bias"] = torch.zeros(width, device=dev)
+            for l in ("ln_1", "ln_2"):
+                sd[q + l + ".weight"] = torch.ones(width, device=dev)
+                sd[q + l + ".bias"] = torch.zeros(width, device=dev)
+
+    blocks("visual.transformer.resblocks.", W, spec.vision_layers)
+    sd["token_embedding.weight"] = n((spec.vocab_size, T), 0.02)
+    sd["positional_embedding"] = n((spec.context_length, T), 0.01)
+    sd["ln_final.weight"] = torch.ones(T, device=dev)
+    sd["ln_final.bias"] = torch.zeros(T, device=dev)
+    sd["text_projection"] = n((T, E), T ** -0.5)
+    sd["logit_scale"] = torch.tensor(math.log(100.0), device=dev)
+    blocks("transformer.resblocks.", T, spec.transformer_layers)
+    return sd
+
+
+def device_pl_state(spec, n_ctx, gen, dev):
+    import torch
+    D = spec.embed_dim
+    sd = {}
+    c = torch.randn((n_ctx, D), generator=gen, device=dev)
+    sd["cls_token"] = c / c.norm(dim=-1, keepdim=True)
+    a, p, f = D ** -0.5, (D ** -0.5) * ((2 * spec.agg_layers) ** -0.5), (2 * D) ** -0.5
+    for i in range(spec.agg_layers):
+        q = f"aggregator.resblocks.{i}."
+        sd[q + "attn.in_proj_weight"] = torch.randn((3 * D, D), generator=gen, device=dev) * a
+        sd[q + "attn.in_proj_bias"] = torch.zeros(3 * D, device=dev)
+        sd[q + "attn.out_proj.weight"] = torch.randn((D, D), generator=gen, device=dev) * p
+        sd[q + "attn.out_proj.bias"] = torch.zeros(D, device=dev)
+        sd[q + "mlp.c_fc.weight"] = torch.randn((4 * D, D), generator=gen, device=dev) * f
+        sd[q + "mlp.c_fc.bias"] = torch.zeros(4 * D, device=dev)
+        sd[q + "mlp.c_proj.weight"] = torch.randn((D, 4 * D), generator=gen, device=dev) * p
+        sd[q + "mlp.c_proj.bias"] = torch.zeros(D, device=dev)
+        for l in ("ln_1", "ln_2"):
+            sd[q + l + ".weight"] = torch.ones(D, device=dev)
+            sd[q + l + ".bias"] = torch.zeros(D, device=dev)
+    return sd
+
+
+def measure_roofline(eng, spec, args, dev):
+    """Dominant kernel = the fp16 MFMA GEMM.  Time the c_fc launch shape (M = batch*tokens, N = 4W, K = W,
+    bias + QuickGELU epilogue) with HIP events on the stream the kernel is launched on (torch's current
+    stream), on random operands.  achieved = 2*M*N*K / mean launch duration."""
+    import ctypes
+    import torch
+    lib = eng.lib
+    M, N, K = args.batch * spec.vision_tokens, 4 * spec.vision_width, spec.vision_width
+    g = torch.Generator(device=dev).manual_seed(7)
+    A = (torch.randn((M, K), generator=g, device=dev) * 0.5).half()
+    Wt = (torch.randn((N, K), generator=g, device=dev) * K ** -0.5).half()
+    b = torch.zeros(N, dtype=torch.float16, device=dev)
+    Cm = torch.empty((M, N), dtype=torch.float16, device=dev)
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+    s = lambda: ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    launch = lambda: lib.ovmr_debug_gemm(0, args.gemm, p(A), p(Wt), p(b), None, None, p(Cm), M, N, K, N, 2, 1.0, 0, 0, s())
+    for _ in range(5):
+        assert launch() == 0
+    torch.cuda.synchronize()
+    reps = 30
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        launch()
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1000.0 / reps
+    flops = 2.0 * M * N * K
+    achieved = flops / (us * 1e-6) / 1e12
+    return {"bound": "mfma", "kernel": f"gemm_f16 variant {args.gemm}, c_fc shape M={M} N={N} K={K} (+bias+QuickGELU)",
+            "achieved": round(achieved, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(achieved / 2500.0, 4),
+            "avg_launch_us": round(us, 2), "flops_per_launch": flops, "traffic": None}
+
+
+def cpu_baseline(spec, sd, pl, tok, args, n_ctx):
+    """The oracle (torch-CPU port of the reference path) on a bounded sample of the same workload:
+    `--cpu-sample-classes` classes x shots through forward_prompt (fp16, the only precision the reference's
+    OVMR path runs in) plus fusion inference on 8 queries; also the encoder alone in fp32.  The faster
+    images/s is reported."""
+    import torch
+    from oracle import ovmr_oracle as O
+    cores = os.cpu_count()
+    torch.set_num_threads(cores)
+    S, Cs = args.shots, args.cpu_sample_classes
+    R = spec.image_resolution
+    cpu_sd = O.convert_weights({k: v.detach().float().cpu() for k, v in sd.items()}, "fp16")
+    cpu_pl = {k: v.detach().float().cpu() for k, v in pl.items()}
+    g = torch.Generator().manual_seed(3)
+    img = torch.randn((Cs * S, 3, R, R), generator=g)
+    q = torch.randn((8, 3, R, R), generator=g)
+    labels = torch.arange(Cs).repeat_interleave(S)
+    with torch.no_grad():
+        O.encode_image(img[:2].half(), cpu_sd)                                    # warm-up
+        t0 = time.perf_counter()
+        r = O.forward_prompt(img, labels, tok[:Cs], cpu_sd, cpu_pl, n_ctx, 10.0, max(1, 256 // S), "fp16")
+        qf = O.l2_normalize(O.encode_image(q.half(), cpu_sd))
+        O.inference_logits(qf, r["mm_classifier"].half(), r["vision_classifier"].half(), r["text_classifier"].half(),
+                           r["fusion_weight"], cpu_sd["logit_scale"].float().exp(), "fusion")
+        t16 = time.perf_counter() - t0
+        sd32 = {k: v.float() for k, v in cpu_sd.items()}
+        t0 = time.perf_counter()
+        O.encode_image(img[:16], sd32)
+        t32 = time.perf_counter() - t0
+    v16 = (Cs * S + 8) / t16
+    v32 = 16 / t32
+    return {"value": round(max(v16, v32), 3), "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": f"{Cs} classes x {S} shots generation + 8 fusion queries in fp16 ({t16:.1f} s, {v16:.2f} img/s); "
+                      f"encoder only, 16 images fp32 ({t32:.1f} s, {v32:.2f} img/s); faster of the two reported",
+            "fp16_images_per_s": round(v16, 3), "fp32_encode_images_per_s": round(v32, 3)}
+
+
+if __name__ == "__main__":
+    main()

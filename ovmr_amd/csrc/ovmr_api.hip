@@ -358,6 +358,7 @@ int ovmr_finalize(ovmr_handle* h, int max_images, int max_prompts, int max_class
 
 int ovmr_encode_image(ovmr_handle* h, const void* image, int image_dtype, int B, void* out_f16, int normalize,
                       ovmr_stream stream) {
+    if (h && B == 0) return 0;   // empty batch: torch hands out a null data_ptr
     if (!h || !image || !out_f16 || B < 0 || (image_dtype != OVMR_F16 && image_dtype != OVMR_F32)) return OVMR_E_ARG;
     if (!h->finalized) return fail(h, OVMR_E_STATE, "ovmr_finalize() has not been called");
     hipStream_t s = (hipStream_t)stream;
@@ -393,6 +394,7 @@ int ovmr_encode_image(ovmr_handle* h, const void* image, int image_dtype, int B,
 
 int ovmr_encode_text_embedded(ovmr_handle* h, const void* prompts_f16, const int32_t* index, int N, int seq_len,
                               void* out_f16, int normalize, ovmr_stream stream) {
+    if (h && N == 0) return 0;
     if (!h || !prompts_f16 || !index || !out_f16 || N < 0 || normalize < 0 || normalize > 2) return OVMR_E_ARG;
     if (!h->finalized) return fail(h, OVMR_E_STATE, "ovmr_finalize() has not been called");
     const ovmr_model_desc& d = h->d;
@@ -416,6 +418,7 @@ int ovmr_encode_text_embedded(ovmr_handle* h, const void* prompts_f16, const int
 
 int ovmr_encode_text_ids(ovmr_handle* h, const int64_t* ids, int N, int seq_len, void* out_f16, int normalize,
                          ovmr_stream stream) {
+    if (h && N == 0) return 0;
     if (!h || !ids || !out_f16 || N < 0 || normalize < 0 || normalize > 2) return OVMR_E_ARG;
     if (!h->finalized) return fail(h, OVMR_E_STATE, "ovmr_finalize() has not been called");
     const ovmr_model_desc& d = h->d;
@@ -439,12 +442,14 @@ int ovmr_encode_text_ids(ovmr_handle* h, const int64_t* ids, int N, int seq_len,
 }
 
 int ovmr_embed_tokens(ovmr_handle* h, const int64_t* ids, int N, int L, void* out_f16, ovmr_stream stream) {
+    if (h && N == 0) return 0;
     if (!h || !ids || !out_f16 || N < 0 || L < 1) return OVMR_E_ARG;
     if (!h->finalized) return fail(h, OVMR_E_STATE, "ovmr_finalize() has not been called");
     return launch_embed_gather(ids, h->tok_emb, (half_t*)out_f16, (long)N * L, h->d.transformer_width, (hipStream_t)stream);
 }
 
 int ovmr_generate_tokens(ovmr_handle* h, const void* feats_f16, int Cb, int S, float* tokens_f32, ovmr_stream stream) {
+    if (h && Cb == 0) return 0;
     if (!h || !feats_f16 || !tokens_f32 || Cb < 0 || S < 1) return OVMR_E_ARG;
     if (!h->finalized) return fail(h, OVMR_E_STATE, "ovmr_finalize() has not been called");
     const ovmr_model_desc& d = h->d;
@@ -469,6 +474,7 @@ int ovmr_generate_tokens(ovmr_handle* h, const void* feats_f16, int Cb, int S, f
 
 int ovmr_assemble_prompts(ovmr_handle* h, const void* base_f16, const int64_t* labels, const float* tokens_f32, int Cb,
                           void* out_f16, ovmr_stream stream) {
+    if (h && Cb == 0) return 0;
     if (!h || !base_f16 || !tokens_f32 || !out_f16 || Cb < 0) return OVMR_E_ARG;
     if (!h->finalized) return fail(h, OVMR_E_STATE, "ovmr_finalize() has not been called");
     if (h->d.embed_dim != h->d.transformer_width)
@@ -480,6 +486,7 @@ int ovmr_assemble_prompts(ovmr_handle* h, const void* base_f16, const int64_t* l
 
 int ovmr_xval_counts(ovmr_handle* h, const void* feats_f16, const int32_t* labels, int R, const void* clf_f16, int C,
                      int32_t* tp, int32_t* n_pred, ovmr_stream stream) {
+    if (h && R == 0) return 0;
     if (!h || !feats_f16 || !labels || !clf_f16 || !tp || !n_pred || R < 0 || C < 1) return OVMR_E_ARG;
     if (!h->finalized) return fail(h, OVMR_E_STATE, "ovmr_finalize() has not been called");
     hipStream_t s = (hipStream_t)stream;
@@ -507,6 +514,7 @@ int ovmr_fusion_weights(ovmr_handle* h, const int32_t* counts, const int32_t* n_
 
 int ovmr_fused_logits(ovmr_handle* h, const void* feats_f16, int B, const void* mm, const void* v, const void* t,
                       const float* w, int C, int mode, float* out_f32, ovmr_stream stream) {
+    if (h && B == 0) return 0;
     if (!h || !feats_f16 || !out_f32 || B < 0 || C < 1) return OVMR_E_ARG;
     if (!h->finalized) return fail(h, OVMR_E_STATE, "ovmr_finalize() has not been called");
     hipStream_t s = (hipStream_t)stream;
@@ -540,6 +548,7 @@ int ovmr_fused_logits(ovmr_handle* h, const void* feats_f16, int B, const void* 
 
 int ovmr_zeroshot_logits(ovmr_handle* h, const void* feats_f16, int B, const void* text_f16, int C, void* out_f16,
                          ovmr_stream stream) {
+    if (h && B == 0) return 0;
     if (!h || !feats_f16 || !text_f16 || !out_f16 || B < 0 || C < 1) return OVMR_E_ARG;
     if (!h->finalized) return fail(h, OVMR_E_STATE, "ovmr_finalize() has not been called");
     hipStream_t s = (hipStream_t)stream;
