@@ -11,73 +11,11 @@
 // C^T: lane l owns row m = l&15 and four CONSECUTIVE columns n = 4*(l>>4)..+3, which turns the
 // epilogue (bias / residual / QuickGELU / positional add) into 8-byte vector loads and stores.
 #include "common.h"
+#include "gemm_epi.h"
 
 namespace {
 
 constexpr int BK = 64;
-
-template <int EPI>
-__device__ __forceinline__ void epilogue_store(const GemmArgs& a, int m, int n, float4_t acc) {
-    if (m >= a.M || n >= a.N) return;
-    half_t* C = (half_t*)a.C;
-    long crow = m;
-    const half_t* posrow = nullptr;
-    if (EPI == EPI_PATCH) {
-        int b = m / a.rows_in, p = m - b * a.rows_in;
-        crow = (long)b * a.rows_out + 1 + p;
-        posrow = (const half_t*)a.pos + (long)(1 + p) * a.N;
-    }
-    const bool vec = (n + 3 < a.N) && ((a.ldc & 3) == 0) && (EPI != EPI_BIAS_RES || (a.ldres & 3) == 0);
-    float bias[4] = {0.f, 0.f, 0.f, 0.f};
-    if (EPI == EPI_BIAS || EPI == EPI_BIAS_QGELU || EPI == EPI_BIAS_RES) {
-        const half_t* bp = (const half_t*)a.bias + n;
-        if (vec) {
-            half4_t b4 = *(const half4_t*)bp;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) bias[r] = (float)b4[r];
-        } else {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) if (n + r < a.N) bias[r] = (float)bp[r];
-        }
-    }
-    float v[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        float x = acc[r];
-        if (EPI == EPI_BIAS || EPI == EPI_BIAS_QGELU || EPI == EPI_BIAS_RES) x = (float)(half_t)(x + bias[r]);
-        else x = (float)(half_t)x;
-        if (EPI == EPI_BIAS_QGELU) x = quick_gelu_h(x);
-        if (EPI == EPI_SCALE) x = x * a.scale;
-        v[r] = x;
-    }
-    half_t* cp = C + crow * a.ldc + n;
-    if (vec) {
-        if (EPI == EPI_BIAS_RES) {
-            half4_t r4 = *(const half4_t*)((const half_t*)a.res + (long)m * a.ldres + n);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] += (float)r4[r];
-        }
-        if (EPI == EPI_PATCH) {
-            half4_t p4 = *(const half4_t*)(posrow + n);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] += (float)p4[r];
-        }
-        half4_t o;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) o[r] = (half_t)v[r];
-        *(half4_t*)cp = o;
-    } else {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            if (n + r < a.N) {
-                float x = v[r];
-                if (EPI == EPI_BIAS_RES) x += (float)((const half_t*)a.res)[(long)m * a.ldres + n + r];
-                if (EPI == EPI_PATCH) x += (float)posrow[n + r];
-                cp[r] = (half_t)x;
-            }
-        }
-    }
-}
 
 // ------------------------------------------------------------------------------------------
 // Variant 0: 128x128x64, register-staged double buffer.

@@ -1,3 +1,156 @@
-// placeholder until the 256x256 8-phase kernel lands
+// fp16 MFMA GEMM, variant 1: (MT*32) x 256 x 64 tile, 8 waves (2 in M x 4 in N), LDS-DMA staging.
+//
+//   * both operands go HBM/L2 -> LDS with global_load_lds_dwordx4 (no VGPR round trip): one wave
+//     instruction moves 8 rows x 128 B; the LDS image is linear per instruction, the XOR swizzle
+//     (16-byte chunk c of row r lives in slot c ^ (r & 7)) is applied to the per-lane SOURCE address
+//     and to the ds_read_b128 address, never to the destination;
+//   * two K-tile buffers of (BM + 256) x 128 B (128 KiB at BM = 256): tile k+1 is in flight while the
+//     64 (BM=256) MFMA 16x16x32 per wave of tile k issue; one vmcnt(0) + barrier per K-tile;
+//   * 1 workgroup per CU, 2 waves per SIMD, 128 accumulator registers per lane (BM = 256);
+//   * a 256-wide N tile halves the L2->LDS bytes per FLOP of the 128x128 kernel (32 B/clk/CU at the
+//     full MFMA rate instead of 64), which is what the 128-square tile is bound by;
+//   * workgroup ids are remapped so that each XCD (private L2) walks a contiguous range of tiles:
+//     tiles that share an A panel run on the same L2.
+// Same epilogues as variant 0 (gemm_epi.h).  BM = 128 (MT = 4) is used when the 256-row grid would
+// leave the 256 CUs badly quantised (N = 768 projections).
 #include "common.h"
-int launch_gemm_f16_v2(const GemmArgs&, hipStream_t) { return -100; }
+#include "gemm_epi.h"
+
+namespace {
+
+constexpr int BK2 = 64;
+constexpr int BN2 = 256;
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+template <int EPI, int MT>
+__global__ __launch_bounds__(512) void gemm_f16_v2_kernel(GemmArgs a, int tiles_m, int tiles_n) {
+    constexpr int BM = MT * 32;
+    constexpr int A_BYTES = BM * 128, STAGE = (BM + BN2) * 128;
+    constexpr int AJ = BM / 64;                     // glds instructions per wave for A (8 rows each)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+
+    // XCD-aware bijective remap (cdna guide 5.5 T1): blocks b, b+8, ... share an XCD
+    const int nwg = tiles_m * tiles_n;
+    int bid = blockIdx.x;
+    {
+        const int xcd = bid & 7, idx = bid >> 3, q = nwg >> 3, r = nwg & 7;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN2;
+
+    const half_t* A = (const half_t*)a.A;
+    const half_t* W = (const half_t*)a.W;
+
+    // staging: lane -> (row within the 8-row group, destination slot); source chunk = slot ^ row
+    const int srow = lane >> 3, slot = lane & 7;
+    const int schunk = (slot ^ srow) * 8;
+    const half_t* ga[AJ];
+    const half_t* gb[4];
+#pragma unroll
+    for (int j = 0; j < AJ; ++j) {
+        const int r = wave * (BM / 8) + j * 8 + srow;
+        ga[j] = A + (long)min(m0 + r, a.M - 1) * a.lda + schunk;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int r = wave * 32 + j * 8 + srow;
+        gb[j] = W + (long)min(n0 + r, a.N - 1) * a.ldw + schunk;
+    }
+    const int ldsA_w = wave * (BM / 8) * 128;       // byte offset of this wave's A rows inside a stage
+    const int ldsB_w = A_BYTES + wave * 32 * 128;
+
+    auto stage = [&](int buf, int kt) {
+        char* base = smem + buf * STAGE;
+#pragma unroll
+        for (int j = 0; j < AJ; ++j)
+            __builtin_amdgcn_global_load_lds((gptr_t)(ga[j] + (long)kt * BK2), (lptr_t)(base + ldsA_w + j * 1024), 16, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            __builtin_amdgcn_global_load_lds((gptr_t)(gb[j] + (long)kt * BK2), (lptr_t)(base + ldsB_w + j * 1024), 16, 0, 0);
+    };
+
+    float4_t acc[MT][4];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (float4_t){0.f, 0.f, 0.f, 0.f};
+
+    const int fr = lane & 15, fg = lane >> 4;
+    const int a_row_off = (wm * (BM / 2) + fr) * 128;
+    const int b_row_off = A_BYTES + (wn * 64 + fr) * 128;
+    const int nk = a.K / BK2;
+
+    stage(0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+        __syncthreads();                              // vmcnt(0) + barrier: tile kt landed, buffer (kt+1)&1 is free
+        if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
+        const char* cur = smem + (kt & 1) * STAGE;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int ch = (((ks << 2) + fg) ^ (fr & 7)) << 4;
+            half8_t fb[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) fb[t] = *(const half8_t*)(cur + b_row_off + t * 2048 + ch);
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                const half8_t fa = *(const half8_t*)(cur + a_row_off + i * 2048 + ch);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[j], fa, acc[i][j], 0, 0, 0);
+            }
+        }
+    }
+
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            epilogue_store<EPI>(a, m0 + wm * (BM / 2) + i * 16 + fr, n0 + wn * 64 + j * 16 + fg * 4, acc[i][j]);
+}
+
+template <int EPI, int MT>
+int launch_v2(const GemmArgs& a, hipStream_t s) {
+    constexpr int BM = MT * 32;
+    const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + BN2 - 1) / BN2;
+    const size_t lds = (size_t)2 * (BM + BN2) * 128;
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIP_CHECK_RET(hipFuncSetAttribute((const void*)gemm_f16_v2_kernel<EPI, MT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm_f16_v2_kernel<EPI, MT>), dim3(tiles_m * tiles_n), dim3(512), lds, s, a, tiles_m, tiles_n);
+    return (int)hipGetLastError();
+}
+
+template <int EPI>
+int pick_v2(const GemmArgs& a, hipStream_t s) {
+    // wave-quantisation: pick the M tile whose grid fills 256 CUs better
+    auto eff = [&](int bm) {
+        const double t = (double)((a.M + bm - 1) / bm) * ((a.N + BN2 - 1) / BN2);
+        return t / (ceil(t / 256.0) * 256.0);
+    };
+    if (eff(256) + 0.08 >= eff(128)) return launch_v2<EPI, 8>(a, s);
+    return launch_v2<EPI, 4>(a, s);
+}
+
+}  // namespace
+
+int launch_gemm_f16_v2(const GemmArgs& a, hipStream_t s) {
+    if (a.M < 256 || a.N < 128) return -100;          // tiny problems stay on the 128x128 kernel
+    switch (a.epi) {
+        case EPI_NONE: return pick_v2<EPI_NONE>(a, s);
+        case EPI_BIAS: return pick_v2<EPI_BIAS>(a, s);
+        case EPI_BIAS_QGELU: return pick_v2<EPI_BIAS_QGELU>(a, s);
+        case EPI_BIAS_RES: return pick_v2<EPI_BIAS_RES>(a, s);
+        case EPI_PATCH: return pick_v2<EPI_PATCH>(a, s);
+        case EPI_SCALE: return pick_v2<EPI_SCALE>(a, s);
+    }
+    return -3;
+}

@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""Times the hot-path GEMM launch shapes for each kernel variant with HIP events on the
+launch stream, interleaving variants in one process (cdna guide rule 24).  Random operands (rule 25).
+
+    python tools/gemm_bench.py [--batch 256] [--variants 0 1] [--rounds 5]
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from ovmr_amd import runtime
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--variants", type=int, nargs="+", default=[0, 1])
+    ap.add_argument("--rounds", type=int, default=5)
+    ap.add_argument("--reps", type=int, default=10)
+    args = ap.parse_args()
+    lib = runtime.load_library()
+    dev = "cuda"
+    M = args.batch * 197
+    shapes = [("qkv", M, 2304, 768, 1), ("out_proj", M, 768, 768, 3), ("c_fc", M, 3072, 768, 2), ("c_proj", M, 768, 3072, 3),
+              ("patch", args.batch * 196, 768, 768, 0), ("text_qkv", 1000 * 10, 1536, 512, 1), ("xval_logits", 16000, 1000, 512, 5)]
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+    s = lambda: ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    out = {}
+    for name, m, n, k, epi in shapes:
+        g = torch.Generator(device=dev).manual_seed(1)
+        A = (torch.randn((m, k), generator=g, device=dev) * 0.5).half()
+        W = (torch.randn((n, k), generator=g, device=dev) * k ** -0.5).half()
+        b = (torch.randn((n,), generator=g, device=dev) * 0.1).half()
+        C = torch.zeros((m, n), dtype=torch.float16, device=dev)
+        res = {}
+        for v in args.variants:
+            for _ in range(3):
+                assert lib.ovmr_debug_gemm(0, v, p(A), p(W), p(b), p(C) if epi == 3 else None, None, p(C), m, n, k, n, epi, 100.0, 0, 0, s()) == 0
+        torch.cuda.synchronize()
+        for r in range(args.rounds):
+            for v in args.variants:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(args.reps):
+                    lib.ovmr_debug_gemm(0, v, p(A), p(W), p(b), p(C) if epi == 3 else None, None, p(C), m, n, k, n, epi, 100.0, 0, 0, s())
+                e1.record()
+                torch.cuda.synchronize()
+                res.setdefault(v, []).append(e0.elapsed_time(e1) * 1000 / args.reps)
+        fl = 2.0 * m * n * k
+        out[name] = {f"v{v}": {"us_median": round(sorted(t)[len(t) // 2], 1), "us_min": round(min(t), 1),
+                               "tflops_median": round(fl / sorted(t)[len(t) // 2] / 1e6, 1)} for v, t in res.items()}
+        print(name, (m, n, k), json.dumps(out[name]), flush=True)
+
+
+if __name__ == "__main__":
+    main()
