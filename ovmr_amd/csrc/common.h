@@ -38,8 +38,9 @@ struct GemmArgs {
 
 __device__ __forceinline__ float quick_gelu_h(float u) {
     // fp16 rounding points of `x * torch.sigmoid(1.702 * x)` on an fp16 tensor
+    // (v_exp_f32 / v_rcp_f32 are 1-ulp fp32 approximations; their result is rounded to fp16 right away)
     half_t t = (half_t)(1.702f * u);
-    half_t s = (half_t)(1.0f / (1.0f + __expf(-(float)t)));
+    half_t s = (half_t)__builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * (float)t));
     return (float)(half_t)(u * (float)s);
 }
 

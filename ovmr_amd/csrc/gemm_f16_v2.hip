@@ -24,7 +24,7 @@ constexpr int BN2 = 256;
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-template <int EPI, int MT>
+template <int EPI, int MT, int PIPE>
 __global__ __launch_bounds__(512) void gemm_f16_v2_kernel(GemmArgs a, int tiles_m, int tiles_n) {
     constexpr int BM = MT * 32;
     constexpr int A_BYTES = BM * 128, STAGE = (BM + BN2) * 128;
@@ -90,20 +90,55 @@ __global__ __launch_bounds__(512) void gemm_f16_v2_kernel(GemmArgs a, int tiles_
     stage(0, 0);
     for (int kt = 0; kt < nk; ++kt) {
         __syncthreads();                              // vmcnt(0) + barrier: tile kt landed, buffer (kt+1)&1 is free
-        if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
+        if (kt + 1 < nk && PIPE != 2) stage((kt + 1) & 1, kt + 1);   // PIPE 2/3: timing-only ablations (tools/gemm_bench.py)
         const char* cur = smem + (kt & 1) * STAGE;
+        if (PIPE != 1) {
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const int ch = (((ks << 2) + fg) ^ (fr & 7)) << 4;
-            half8_t fb[4];
+            for (int ks = 0; ks < 2; ++ks) {
+                const int ch = (((ks << 2) + fg) ^ (fr & 7)) << 4;
+                half8_t fb[4];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) fb[t] = *(const half8_t*)(cur + b_row_off + t * 2048 + ch);
+                for (int t = 0; t < 4; ++t) fb[t] = *(const half8_t*)(cur + b_row_off + t * 2048 + ch);
 #pragma unroll
-            for (int i = 0; i < MT; ++i) {
-                const half8_t fa = *(const half8_t*)(cur + a_row_off + i * 2048 + ch);
+                for (int i = 0; i < MT; ++i) {
+                    const half8_t fa = *(const half8_t*)(cur + a_row_off + i * 2048 + ch);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        if (PIPE == 3) asm volatile("" ::"v"(fb[j]), "v"(fa));
+                        else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[j], fa, acc[i][j], 0, 0, 0);
+                    }
+                }
+            }
+        } else {
+            // software-pipelined fragment reads: the A fragment of step t+2 and the B fragments of the next
+            // k-step are issued before the MFMAs of step t, so no MFMA group waits a full LDS round trip
+            const int ch0 = ((fg) ^ (fr & 7)) << 4, ch1 = ((4 + fg) ^ (fr & 7)) << 4;
+            half8_t fb[2][4], fa[3];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) fb[0][t] = *(const half8_t*)(cur + b_row_off + t * 2048 + ch0);
+            fa[0] = *(const half8_t*)(cur + a_row_off + ch0);
+            fa[1] = *(const half8_t*)(cur + a_row_off + 2048 + ch0);
+#pragma unroll
+            for (int st = 0; st < 2 * MT; ++st) {
+                const int nx = st + 2;
+                if (nx < 2 * MT)
+                    fa[nx % 3] = *(const half8_t*)(cur + a_row_off + (nx % MT) * 2048 + (nx / MT ? ch1 : ch0));
+                if (st == 1) {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) fb[1][t] = *(const half8_t*)(cur + b_row_off + t * 2048 + ch1);
+                }
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[j], fa, acc[i][j], 0, 0, 0);
+                    acc[st % MT][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[st / MT][j], fa[st % 3], acc[st % MT][j], 0, 0, 0);
+            }
+            // pin that order for the machine scheduler (it otherwise sinks every read next to its first use
+            // behind an lgkmcnt(0)): 6 reads up front, then {1 read (5 at step 1), 4 MFMA} per step
+            __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+#pragma unroll
+            for (int st = 0; st < 2 * MT; ++st) {
+                if (st == 1) __builtin_amdgcn_sched_group_barrier(0x100, 5, 0);
+                else if (st + 2 < 2 * MT) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
             }
         }
     }
@@ -115,42 +150,49 @@ __global__ __launch_bounds__(512) void gemm_f16_v2_kernel(GemmArgs a, int tiles_
             epilogue_store<EPI>(a, m0 + wm * (BM / 2) + i * 16 + fr, n0 + wn * 64 + j * 16 + fg * 4, acc[i][j]);
 }
 
-template <int EPI, int MT>
+template <int EPI, int MT, int PIPE>
 int launch_v2(const GemmArgs& a, hipStream_t s) {
     constexpr int BM = MT * 32;
     const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + BN2 - 1) / BN2;
     const size_t lds = (size_t)2 * (BM + BN2) * 128;
     static bool attr_set = false;
     if (!attr_set) {
-        HIP_CHECK_RET(hipFuncSetAttribute((const void*)gemm_f16_v2_kernel<EPI, MT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIP_CHECK_RET(hipFuncSetAttribute((const void*)gemm_f16_v2_kernel<EPI, MT, PIPE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_f16_v2_kernel<EPI, MT>), dim3(tiles_m * tiles_n), dim3(512), lds, s, a, tiles_m, tiles_n);
+    hipLaunchKernelGGL((gemm_f16_v2_kernel<EPI, MT, PIPE>), dim3(tiles_m * tiles_n), dim3(512), lds, s, a, tiles_m, tiles_n);
     return (int)hipGetLastError();
 }
 
-template <int EPI>
+template <int EPI, int PIPE>
 int pick_v2(const GemmArgs& a, hipStream_t s) {
     // wave-quantisation: pick the M tile whose grid fills 256 CUs better
     auto eff = [&](int bm) {
         const double t = (double)((a.M + bm - 1) / bm) * ((a.N + BN2 - 1) / BN2);
         return t / (ceil(t / 256.0) * 256.0);
     };
-    if (eff(256) + 0.08 >= eff(128)) return launch_v2<EPI, 8>(a, s);
-    return launch_v2<EPI, 4>(a, s);
+    if (eff(256) + 0.08 >= eff(128)) return launch_v2<EPI, 8, PIPE>(a, s);
+    return launch_v2<EPI, 4, PIPE>(a, s);
 }
 
 }  // namespace
 
-int launch_gemm_f16_v2(const GemmArgs& a, hipStream_t s) {
-    if (a.M < 256 || a.N < 128) return -100;          // tiny problems stay on the 128x128 kernel
+template <int PIPE>
+int dispatch_v2(const GemmArgs& a, hipStream_t s) {
     switch (a.epi) {
-        case EPI_NONE: return pick_v2<EPI_NONE>(a, s);
-        case EPI_BIAS: return pick_v2<EPI_BIAS>(a, s);
-        case EPI_BIAS_QGELU: return pick_v2<EPI_BIAS_QGELU>(a, s);
-        case EPI_BIAS_RES: return pick_v2<EPI_BIAS_RES>(a, s);
-        case EPI_PATCH: return pick_v2<EPI_PATCH>(a, s);
-        case EPI_SCALE: return pick_v2<EPI_SCALE>(a, s);
+        case EPI_NONE: return pick_v2<EPI_NONE, PIPE>(a, s);
+        case EPI_BIAS: return pick_v2<EPI_BIAS, PIPE>(a, s);
+        case EPI_BIAS_QGELU: return pick_v2<EPI_BIAS_QGELU, PIPE>(a, s);
+        case EPI_BIAS_RES: return pick_v2<EPI_BIAS_RES, PIPE>(a, s);
+        case EPI_PATCH: return pick_v2<EPI_PATCH, PIPE>(a, s);
+        case EPI_SCALE: return pick_v2<EPI_SCALE, PIPE>(a, s);
     }
     return -3;
+}
+
+int launch_gemm_f16_v2(const GemmArgs& a, int pipe, hipStream_t s) {
+    if (a.M < 256 || a.N < 128) return -100;          // tiny problems stay on the 128x128 kernel
+    if (pipe == 2) return launch_v2<EPI_BIAS, 8, 2>(a, s);   // ablation: no loads after the first K-tile
+    if (pipe == 3) return launch_v2<EPI_BIAS, 8, 3>(a, s);   // ablation: no MFMA
+    return pipe ? dispatch_v2<1>(a, s) : dispatch_v2<0>(a, s);
 }

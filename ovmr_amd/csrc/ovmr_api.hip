@@ -35,7 +35,7 @@ struct ovmr_handle {
     std::vector<void*> owned;
     std::string err;
     bool finalized = false;
-    int gemm_variant = 0, attn_variant = 0;
+    int gemm_variant = 6, attn_variant = 0;   // defaults = fastest verified kernels (tools/gemm_bench.py)
     float logit_scale_exp = 100.f;
     bool have_logit_scale = false;
 
