@@ -1,0 +1,167 @@
+"""N > 1 path on CPU: two gloo ranks run the REAL orchestration code (ovmr_amd.modules.CustomCLIP.forward_prompt:
+batch sharding, all-gather of packed classifier rows, all-reduce of the F1 counters) on top of a test-only engine
+that answers the Engine calls with the CPU oracle.  The result must equal the single-process result.
+(The product Engine has no CPU path; this stand-in lives in tests/ only.)"""
+import os
+import socket
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import REPO
+from ovmr_amd import synth
+
+SEED, N_CTX, S, C = 11, 2, 4, 6
+
+
+class OracleEngine:
+    """Implements the subset of ovmr_amd.runtime.Engine that modules.py calls, with oracle/ovmr_oracle.py."""
+
+    def __init__(self, spec, n_ctx):
+        from oracle import ovmr_oracle as O
+        self.O, self.spec, self.n_ctx = O, spec, n_ctx
+        self.device = torch.device("cpu")
+        self.finalized = False
+        self.sd = O.convert_weights(O.to_torch(synth.clip_state_dict(spec, SEED, jitter=True)), "fp16")
+        self.pl = {}
+        self.logit_scale = float(self.sd["logit_scale"].exp())
+
+    def set_weight(self, name, t):
+        if name.startswith("prompt_learner."):
+            self.pl[name[len("prompt_learner."):]] = t.float()
+
+    def finalize(self, *a):
+        self.finalized = True
+
+    def embed_tokens(self, ids):
+        return self.O.prompt_embeddings(ids, self.sd)
+
+    def encode_text_ids(self, ids, seq_len=None, normalize=0):
+        with torch.no_grad():
+            t = self.O.encode_text(ids, self.sd)
+        return self.O.l2_normalize(t) if normalize else t
+
+    def encode_image(self, img, normalize=True, out=None):
+        with torch.no_grad():
+            f = self.O.encode_image(img.half(), self.sd)
+        return self.O.l2_normalize(f) if normalize else f
+
+    def generate_tokens(self, feats):
+        O = self.O
+        with torch.no_grad():
+            cls = self.pl["cls_token"].unsqueeze(0).repeat(feats.shape[0], 1, 1)
+            x = torch.cat([cls, feats.float()], dim=1)
+            return O.transformer(x, self.pl, "aggregator.resblocks.", feats.shape[-1] // 64, None)[:, :self.n_ctx]
+
+    def assemble_prompts(self, base, labels, tokens):
+        src = base[labels.long()] if labels is not None else base[:1].repeat(tokens.shape[0], 1, 1)
+        return self.O.update_prompts(src, tokens, self.n_ctx)
+
+    def encode_text_embedded(self, prompts, index, seq_len=None, normalize=0):
+        with torch.no_grad():
+            t = self.O.text_encoder_forward(prompts, index, self.sd)
+        for _ in range(normalize):
+            t = self.O.l2_normalize(t)
+        return t
+
+    def xval_counts(self, feats, labels, clf, tp, n_pred):
+        lg = (self.logit_scale * (feats @ clf.t())).float()
+        pred = lg.argmax(1)
+        n_pred += torch.bincount(pred, minlength=clf.shape[0]).int()
+        tp += torch.bincount(labels.long()[pred == labels.long()], minlength=clf.shape[0]).int()
+
+    def fusion_weights(self, counts, n_label, tau):
+        f1 = torch.stack([self.O.f1_from_counts(counts[m, 0], counts[m, 1], n_label) for m in range(3)], -1)
+        return (tau * f1).softmax(-1)
+
+    def fused_logits(self, f, mm, v, t, w, mode):
+        return self.O.inference_logits(f, mm, v, t, w, torch.tensor(self.logit_scale), mode)
+
+
+class FakeCLIPModel:
+    def __init__(self, spec):
+        self.spec, self.dtype = spec, torch.float16
+        self._e = {}
+        self.logit_scale = torch.tensor(float(np.log(100.0)))
+
+    def engine(self, n_ctx):
+        if n_ctx not in self._e:
+            self._e[n_ctx] = OracleEngine(self.spec, n_ctx)
+        return self._e[n_ctx]
+
+
+def _run(rank, world, port, outdir, result):
+    sys.path.insert(0, REPO)
+    torch.set_num_threads(2)
+    if world > 1:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    from ovmr_amd import modules
+    spec = synth.SPECS["tiny"]
+    cfg = modules.make_cfg(n_ctx=N_CTX, num_shots=S, output_dir=outdir if rank == 0 else "")
+    pl = {k: torch.from_numpy(v) for k, v in synth.prompt_learner_state_dict(spec, N_CTX, SEED, True).items()}
+    tok = torch.from_numpy(synth.class_token_ids(C, seed=4321))
+    model = modules.CustomCLIP(cfg, tok, FakeCLIPModel(spec), prompt_learner_state=pl, reserve=(8, 8, 8))
+    labels = np.repeat(np.array([3, 0, 5, 1, 2, 4]), S)
+    img = torch.from_numpy(synth.images(C * S, spec.image_resolution, 1234, labels, 0.6))
+    loader = [{"img": img[s:s + S], "label": torch.from_numpy(labels[s:s + S])} for s in range(0, C * S, S)]  # 6 batches
+    q = torch.from_numpy(synth.images(5, spec.image_resolution, 777))
+    out = model(q, eval_set_loader=loader)
+    if rank == 0:
+        torch.save({"out": out, "mm": model.mm_classifier, "v": model.visual_classifer, "t": model.zero_shot_classifier,
+                    "w": model.fusion_weight, "counts": model.xval_counts, "tokens": model.visual_tokens}, result)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+@pytest.mark.timeout(600)
+def test_two_rank_generation_matches_single_process():
+    with tempfile.TemporaryDirectory() as d:
+        r1, r2 = os.path.join(d, "single.pt"), os.path.join(d, "dist.pt")
+        _run(0, 1, 0, os.path.join(d, "o1"), r1)
+        mp.spawn(_run, args=(2, _free_port(), os.path.join(d, "o2"), r2), nprocs=2, join=True)
+        a, b = torch.load(r1), torch.load(r2)
+        for k in ("mm", "v", "t", "tokens"):
+            assert torch.equal(a[k], b[k]), k                      # rows are computed independently per class
+        assert torch.equal(a["counts"], b["counts"])               # int32 counters summed over ranks
+        assert torch.allclose(a["w"], b["w"], atol=0)
+        assert torch.allclose(a["out"], b["out"], atol=1e-6)
+        saved = torch.load(os.path.join(d, "o2", "mm_classifiers.pt"))
+        assert sorted(saved) == ["fusion_weight", "mm_classifier", "text_classifier", "vision_classifier"]
+
+
+def _gather(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, REPO)
+    from ovmr_amd.shard import all_gather_rows, shard_range
+    full = torch.arange(7 * 3, dtype=torch.float16).reshape(7, 3)
+    a, b = shard_range(7, rank, world)                              # ragged: 4 + 3 rows
+    rows, labels = all_gather_rows(full[a:b], torch.arange(a, b), dist)
+    out = torch.zeros_like(full)
+    out[labels] = rows
+    ok = torch.equal(out, full) and sorted(labels.tolist()) == list(range(7))
+    if rank == 0:
+        q.put(ok)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_ragged_all_gather_rows():
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    mp.spawn(_gather, args=(2, _free_port(), q), nprocs=2, join=True)
+    assert q.get() is True
