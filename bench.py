@@ -40,9 +40,9 @@ def parse():
     ap.add_argument("--shots", type=int, default=16)
     ap.add_argument("--queries", type=int, default=4096)
     ap.add_argument("--batch", type=int, default=256, help="images per encoder launch sequence (TEST.BATCH_SIZE)")
-    ap.add_argument("--classes-per-batch", type=int, default=64)
+    ap.add_argument("--classes-per-batch", type=int, default=256)
     ap.add_argument("--gemm", type=int, default=int(os.environ.get("OVMR_GEMM", "6")))
-    ap.add_argument("--attn", type=int, default=int(os.environ.get("OVMR_ATTN", "0")))
+    ap.add_argument("--attn", type=int, default=int(os.environ.get("OVMR_ATTN", "1")))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-classes", type=int, default=16)
     return ap.parse_args()

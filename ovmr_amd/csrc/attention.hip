@@ -21,7 +21,8 @@ constexpr int VT_LD = 68;   // halves per V^T row (64 keys + 4 pad -> 136 B)
 
 template <bool CAUSAL>
 __global__ __launch_bounds__(256) void attn_f16_v0(const half_t* __restrict__ qkv, half_t* __restrict__ out,
-                                                   int L, int H, int nT, int nWG, float scale_log2e) {
+                                                   int L, int Lq, int H, int nT, int nWG, float scale_log2e) {
+    // Lq <= L: only the first Lq query rows of every sequence are computed, output rows are b*Lq + q
     __shared__ __attribute__((aligned(16))) half_t sK[KB * 64];
     __shared__ __attribute__((aligned(16))) half_t sVt[64 * VT_LD];
 
@@ -134,9 +135,9 @@ __global__ __launch_bounds__(256) void attn_f16_v0(const half_t* __restrict__ qk
             }
         }
     }
-    if (active && q < L) {
+    if (active && q < Lq) {
         const float inv = 1.0f / l_run;
-        half_t* op = out + ((long)b * L + q) * D + h * 64 + fg * 4;
+        half_t* op = out + ((long)b * Lq + q) * D + h * 64 + fg * 4;
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
             half4_t w = {(half_t)(o[dt][0] * inv), (half_t)(o[dt][1] * inv), (half_t)(o[dt][2] * inv), (half_t)(o[dt][3] * inv)};
@@ -192,19 +193,24 @@ __global__ __launch_bounds__(128) void attn_f32_small(const float* __restrict__ 
 
 }  // namespace
 
-int launch_attention_f16_v1(const half_t* qkv, half_t* out, int B, int L, int H, int causal, hipStream_t s);  // attention_v1.hip
+int launch_attention_f16_v1(const half_t* qkv, half_t* out, int B, int L, int Lq, int H, int causal, hipStream_t s);  // attention_v1.hip
 
 int launch_attention_f16(const half_t* qkv, half_t* out, int B, int L, int H, int causal, int variant, hipStream_t s) {
-    if (B <= 0 || L <= 0) return 0;
+    return launch_attention_f16_q(qkv, out, B, L, L, H, causal, variant, s);
+}
+
+int launch_attention_f16_q(const half_t* qkv, half_t* out, int B, int L, int Lq, int H, int causal, int variant, hipStream_t s) {
+    if (B <= 0 || L <= 0 || Lq <= 0) return 0;
+    if (Lq > L) return -2;
     if (variant == 1) {
-        int rc = launch_attention_f16_v1(qkv, out, B, L, H, causal, s);
+        int rc = launch_attention_f16_v1(qkv, out, B, L, Lq, H, causal, s);
         if (rc != -100) return rc;
     }
-    const int nT = (L + 15) / 16, nWG = (nT + 3) / 4;
+    const int nT = (Lq + 15) / 16, nWG = (nT + 3) / 4;
     const float sl2e = 0.125f * 1.4426950408889634f;   // hd^-0.5 * log2(e), hd = 64
     const dim3 grid((unsigned)((long)B * H * nWG));
-    if (causal) hipLaunchKernelGGL(attn_f16_v0<true>, grid, dim3(256), 0, s, qkv, out, L, H, nT, nWG, sl2e);
-    else hipLaunchKernelGGL(attn_f16_v0<false>, grid, dim3(256), 0, s, qkv, out, L, H, nT, nWG, sl2e);
+    if (causal) hipLaunchKernelGGL(attn_f16_v0<true>, grid, dim3(256), 0, s, qkv, out, L, Lq, H, nT, nWG, sl2e);
+    else hipLaunchKernelGGL(attn_f16_v0<false>, grid, dim3(256), 0, s, qkv, out, L, Lq, H, nT, nWG, sl2e);
     return (int)hipGetLastError();
 }
 

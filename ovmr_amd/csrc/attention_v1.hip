@@ -1,2 +1,170 @@
+// Attention variant 1 (fp16, hd = 64): same swapped-product flash structure as attention.hip, with
+//   * K and V blocks staged by LDS-DMA (global_load_lds_dwordx4) into a DOUBLE buffer: block k+1 is in
+//     flight while block k is consumed, no VGPR staging and no transposing LDS writes;
+//   * V kept row-major [key][d] like K (128-byte rows, chunk c of row r in slot c ^ (r & 7)) and consumed
+//     through ds_read_b64_tr_b16: per 16-lane group the instruction reads 4 keys x 16 d and hands lane i
+//     the 4 keys of column d0+i -- exactly the V^T fragment (A operand of O^T = V^T P^T);
+//   * two 16-row query tiles per wave (8 per workgroup): K/V of a (sequence, head) are staged 2x instead
+//     of 4x at L = 197.
 #include "common.h"
-int launch_attention_f16_v1(const half_t*, half_t*, int, int, int, int, hipStream_t) { return -100; }
+
+namespace {
+
+constexpr int KB1 = 64;
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+typedef short short4v __attribute__((__vector_size__(8)));
+
+__device__ __forceinline__ half4_t tr_read(const half_t* p) {
+    short4v r = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)p);
+    return __builtin_bit_cast(half4_t, r);
+}
+
+template <bool CAUSAL>
+__global__ __launch_bounds__(256) void attn_f16_v1(const half_t* __restrict__ qkv, half_t* __restrict__ out,
+                                                   int L, int Lq, int H, int nT, int nWG, float scale_log2e) {
+    __shared__ __attribute__((aligned(16))) half_t smem[2 * 2 * KB1 * 64];   // [buf][K|V][64 keys][64 d]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, fg = lane >> 4;
+    const int D = H * 64, ld = 3 * D;
+    const int wg = blockIdx.x % nWG, bh = blockIdx.x / nWG;
+    const int h = bh % H, b = bh / H;
+    const int t0 = (wg * nT) / nWG, t1 = ((wg + 1) * nT) / nWG;        // up to 8 query tiles
+    const half_t* base = qkv + (long)b * L * ld + h * 64;
+
+    int qrow[2];
+    bool act[2];
+    half8_t qf[2][2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int qt = t0 + wave + 4 * u;
+        act[u] = qt < t1;
+        qrow[u] = qt * 16 + fr;
+        const int qc = min(qrow[u], L - 1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) qf[u][ks] = *(const half8_t*)(base + (long)qc * ld + ks * 32 + fg * 8);
+    }
+    float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.f, 0.f};
+    float4_t o[2][4];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[u][i] = (float4_t){0.f, 0.f, 0.f, 0.f};
+
+    // staging: 16 LDS-DMA instructions per block (8 K + 8 V), 4 per wave; one instruction = 8 rows x 128 B
+    const int srow = lane >> 3, schunk = ((lane & 7) ^ srow) * 8;
+    auto stage = [&](int buf, int k0) {
+        half_t* dst = smem + buf * (2 * KB1 * 64);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int ins = wave * 4 + j;                 // 0..7: K rows, 8..15: V rows
+            const int isv = ins >> 3, r0 = (ins & 7) * 8;
+            const int kc = min(k0 + r0 + srow, L - 1);
+            __builtin_amdgcn_global_load_lds((gptr_t)(base + (1 + isv) * D + (long)kc * ld + schunk),
+                                             (lptr_t)(dst + isv * (KB1 * 64) + r0 * 64), 16, 0, 0);
+        }
+    };
+
+    const int last_tile = min(t1 - 1, t0 + 7);
+    const int kmax = CAUSAL ? min(L, (last_tile + 1) * 16) : L;
+    const int nb = (kmax + KB1 - 1) / KB1;
+    stage(0, 0);
+    for (int kb = 0; kb < nb; ++kb) {
+        __syncthreads();                                   // vmcnt(0) + barrier: block kb landed, other buffer free
+        if (kb + 1 < nb) stage((kb + 1) & 1, (kb + 1) * KB1);
+        const half_t* sK = smem + (kb & 1) * (2 * KB1 * 64);
+        const half_t* sV = sK + KB1 * 64;
+        const int k0 = kb * KB1;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (!act[u] || (CAUSAL && k0 > (t0 + wave + 4 * u) * 16 + 15)) continue;     // wave-uniform
+            const int q = qrow[u];
+            float4_t s[4];
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                s[nt] = (float4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    half8_t kf = *(const half8_t*)(sK + (nt * 16 + fr) * 64 + ((((ks << 2) + fg) ^ (fr & 7)) << 3));
+                    s[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[u][ks], s[nt], 0, 0, 0);
+                }
+            }
+            float mx = -INFINITY;
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int key = k0 + nt * 16 + fg * 4 + r;
+                    const bool ok = (key < L) && (!CAUSAL || key <= q);
+                    const float v = ok ? s[nt][r] * scale_log2e : -INFINITY;
+                    s[nt][r] = v;
+                    mx = fmaxf(mx, v);
+                }
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float m_new = fmaxf(m_run[u], mx);
+            const float alpha = exp2f(m_run[u] - m_new);
+            float psum = 0.f;
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float p = exp2f(s[nt][r] - m_new);
+                    s[nt][r] = p;
+                    psum += p;
+                }
+            psum += __shfl_xor(psum, 16, 64);
+            psum += __shfl_xor(psum, 32, 64);
+            l_run[u] = l_run[u] * alpha + psum;
+            m_run[u] = m_new;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) o[u][dt] *= alpha;
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                half8_t pf;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    pf[j] = (half_t)s[2 * s2][j];
+                    pf[4 + j] = (half_t)s[2 * s2 + 1][j];
+                }
+                // V^T fragment through the transposing read: lane (fr, fg) addresses key row kr, 4 d-columns
+                const int kr = s2 * 32 + fg * 4 + (fr >> 2);
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    const int c = dt * 2 + ((fr & 3) >> 1);
+                    const int off = (((c ^ (kr & 7)) << 3) + (fr & 1) * 4);      // halves; (kr+16)&7 == kr&7
+                    half4_t v0 = tr_read(sV + kr * 64 + off);
+                    half4_t v1 = tr_read(sV + (kr + 16) * 64 + off);
+                    half8_t vf = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                    o[u][dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf, o[u][dt], 0, 0, 0);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        if (act[u] && qrow[u] < Lq) {
+            const float inv = 1.0f / l_run[u];
+            half_t* op = out + ((long)b * Lq + qrow[u]) * D + h * 64 + fg * 4;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                half4_t w = {(half_t)(o[u][dt][0] * inv), (half_t)(o[u][dt][1] * inv), (half_t)(o[u][dt][2] * inv),
+                             (half_t)(o[u][dt][3] * inv)};
+                *(half4_t*)(op + dt * 16) = w;
+            }
+        }
+    }
+}
+
+}  // namespace
+
+int launch_attention_f16_v1(const half_t* qkv, half_t* out, int B, int L, int Lq, int H, int causal, hipStream_t s) {
+    const int nT = (Lq + 15) / 16, nWG = (nT + 7) / 8;
+    const float sl2e = 0.125f * 1.4426950408889634f;
+    const dim3 grid((unsigned)((long)B * H * nWG));
+    if (causal) hipLaunchKernelGGL(attn_f16_v1<true>, grid, dim3(256), 0, s, qkv, out, L, Lq, H, nT, nWG, sl2e);
+    else hipLaunchKernelGGL(attn_f16_v1<false>, grid, dim3(256), 0, s, qkv, out, L, Lq, H, nT, nWG, sl2e);
+    return (int)hipGetLastError();
+}

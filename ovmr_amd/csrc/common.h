@@ -67,6 +67,7 @@ int launch_gemm_f32(const GemmArgs& a, hipStream_t s);
 int launch_layernorm(const void* x, void* y, const float* g, const float* b, int rows, int D,
                      long in_row_stride, int is_f32, hipStream_t s);
 int launch_attention_f16(const half_t* qkv, half_t* out, int B, int L, int H, int causal, int variant, hipStream_t s);
+int launch_attention_f16_q(const half_t* qkv, half_t* out, int B, int L, int Lq, int H, int causal, int variant, hipStream_t s);
 int launch_attention_f32(const float* qkv, float* out, int B, int L, int H, hipStream_t s);
 int launch_im2col(const void* img, int img_is_f32, half_t* out, int B, int R, int P, int Kpad, hipStream_t s);
 int launch_fill_cls(half_t* x, const half_t* cls_pos, int B, int L, int W, hipStream_t s);
