@@ -66,11 +66,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    dev = torch.device(f"cuda:{local}")
+    # one GPU per rank; OVMR_DIST_BACKEND=gloo lets several ranks share one device to exercise the N > 1 path on a 1-GPU box
+    backend = os.environ.get("OVMR_DIST_BACKEND", "nccl")
+    dev = torch.device(f"cuda:{local if backend == 'nccl' else local % max(1, torch.cuda.device_count())}")
     torch.cuda.set_device(dev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     spec = synth.SPECS[args.model]
     C, S, Q, n_ctx = args.classes, args.shots, args.queries, 2

@@ -202,7 +202,7 @@ int launch_attention_f16(const half_t* qkv, half_t* out, int B, int L, int H, in
 int launch_attention_f16_q(const half_t* qkv, half_t* out, int B, int L, int Lq, int H, int causal, int variant, hipStream_t s) {
     if (B <= 0 || L <= 0 || Lq <= 0) return 0;
     if (Lq > L) return -2;
-    if (variant == 1) {
+    if (variant == 1 && L >= 128) {   // short (text) sequences: one key block, the plain kernel is faster (tools/attn_bench.py)
         int rc = launch_attention_f16_v1(qkv, out, B, L, Lq, H, causal, s);
         if (rc != -100) return rc;
     }

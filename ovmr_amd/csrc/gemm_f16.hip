@@ -128,13 +128,14 @@ int launch_t128(const GemmArgs& a, hipStream_t s) {
 
 int launch_gemm_f16_v2(const GemmArgs& a, int pipe, hipStream_t s);     // gemm_f16_v2.hip (256x256x64 LDS-DMA; pipe: pipelined fragment reads)
 int launch_gemm_f16_v3(const GemmArgs& a, int variant, hipStream_t s);  // gemm_f16_v3.hip (LDS-DMA ring, counted vmcnt)
-int launch_gemm_f16_v5(const GemmArgs& a, int variant, hipStream_t s);  // gemm_f16_v5.hip (L2 prefetch + LDS-staged epilogue)
+int launch_gemm_f16_v5(const GemmArgs& a, int variant, hipStream_t s);
+int launch_gemm_f16_v7(const GemmArgs& a, hipStream_t s);               // gemm_f16_v7.hip (4-slot ring, register double-buffered fragments)  // gemm_f16_v5.hip (L2 prefetch + LDS-staged epilogue)
 
 int launch_gemm_f16(const GemmArgs& a, int variant, hipStream_t s) {
     if (a.M <= 0 || a.N <= 0) return 0;
     if (a.K <= 0 || (a.K % BK) != 0 || (a.lda & 7) || (a.ldw & 7)) return -2;  // caller pads K to 64
     if (variant >= 1) {
-        int rc = (variant >= 5 && variant <= 10) ? launch_gemm_f16_v5(a, variant, s) : variant == 1 ? launch_gemm_f16_v2(a, 0, s) : variant == 4 ? launch_gemm_f16_v2(a, 1, s) : variant >= 12 ? launch_gemm_f16_v2(a, variant - 10, s) : launch_gemm_f16_v3(a, variant, s);
+        int rc = variant == 11 ? launch_gemm_f16_v7(a, s) : (variant >= 5 && variant <= 10) ? launch_gemm_f16_v5(a, variant, s) : variant == 1 ? launch_gemm_f16_v2(a, 0, s) : variant == 4 ? launch_gemm_f16_v2(a, 1, s) : variant >= 12 ? launch_gemm_f16_v2(a, variant - 10, s) : launch_gemm_f16_v3(a, variant, s);
         if (rc != -100) return rc;   // -100: shape not supported -> fall through to t128
     }
     switch (a.epi) {

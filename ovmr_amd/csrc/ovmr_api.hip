@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -602,6 +603,10 @@ int ovmr_debug_gemm(int f32, int variant, const void* A, const void* W, const vo
                     const void* pos, void* C, int M, int N, int K, int ldc, int epi, float scale,
                     int rows_in, int rows_out, ovmr_stream stream) {
     GemmArgs a = gemm(A, K, W, K, C, ldc, M, N, K, epi, bias, res, ldc);
+    if (const char* e = getenv("OVMR_DEBUG_LDPAD")) {   // stride experiment (tools/gemm_bench.py --ldpad): operands have padded rows
+        a.lda = K + atoi(e);
+        a.ldw = K + atoi(e);
+    }
     a.pos = pos; a.scale = scale; a.rows_in = rows_in; a.rows_out = rows_out;
     return f32 ? launch_gemm_f32(a, (hipStream_t)stream) : launch_gemm_f16(a, variant, (hipStream_t)stream);
 }

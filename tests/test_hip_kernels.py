@@ -10,7 +10,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 EPI_NONE, EPI_BIAS, EPI_BIAS_QGELU, EPI_BIAS_RES, EPI_PATCH, EPI_SCALE = range(6)
-GEMM_VARIANTS = [0, 1, 2, 3, 4, 6, 8, 9, 10]
+GEMM_VARIANTS = [0, 1, 2, 3, 4, 6, 8, 9, 10, 11]
 ATTN_VARIANTS = [0, 1]
 
 

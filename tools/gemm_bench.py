@@ -21,7 +21,10 @@ def main():
     ap.add_argument("--variants", type=int, nargs="+", default=[0, 1])
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--reps", type=int, default=10)
+    ap.add_argument("--ldpad", type=int, default=0, help="row padding (halves) of A and W: stride experiment")
     args = ap.parse_args()
+    if args.ldpad:
+        os.environ["OVMR_DEBUG_LDPAD"] = str(args.ldpad)
     lib = runtime.load_library()
     dev = "cuda"
     M = args.batch * 197
@@ -32,8 +35,8 @@ def main():
     out = {}
     for name, m, n, k, epi in shapes:
         g = torch.Generator(device=dev).manual_seed(1)
-        A = (torch.randn((m, k), generator=g, device=dev) * 0.5).half()
-        W = (torch.randn((n, k), generator=g, device=dev) * k ** -0.5).half()
+        A = (torch.randn((m, k + args.ldpad), generator=g, device=dev) * 0.5).half()
+        W = (torch.randn((n, k + args.ldpad), generator=g, device=dev) * k ** -0.5).half()
         b = (torch.randn((n,), generator=g, device=dev) * 0.1).half()
         C = torch.zeros((m, n), dtype=torch.float16, device=dev)
         res = {}
