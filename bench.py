@@ -39,7 +39,7 @@ def parse():
     ap.add_argument("--classes", type=int, default=1000)
     ap.add_argument("--shots", type=int, default=16)
     ap.add_argument("--queries", type=int, default=4096)
-    ap.add_argument("--batch", type=int, default=256, help="images per encoder launch sequence (TEST.BATCH_SIZE)")
+    ap.add_argument("--batch", type=int, default=512, help="images per encoder launch sequence")
     ap.add_argument("--classes-per-batch", type=int, default=256)
     ap.add_argument("--gemm", type=int, default=int(os.environ.get("OVMR_GEMM", "6")))
     ap.add_argument("--attn", type=int, default=int(os.environ.get("OVMR_ATTN", "1")))
