@@ -72,7 +72,10 @@ __global__ __launch_bounds__(256) void attn_f16_v1(const half_t* __restrict__ qk
     const int nb = (kmax + KB1 - 1) / KB1;
     stage(0, 0);
     for (int kb = 0; kb < nb; ++kb) {
-        __syncthreads();                                   // vmcnt(0) + barrier: block kb landed, other buffer free
+        // every wave must have its own LDS-DMA of block kb retired BEFORE the barrier (hipcc does not always put the
+        // vmcnt(0) of __syncthreads() ahead of the barrier: it was found sunk to the first V read, a cross-wave race)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                                   // block kb landed for all waves, other buffer free
         if (kb + 1 < nb) stage((kb + 1) & 1, (kb + 1) * KB1);
         const half_t* sK = smem + (kb & 1) * (2 * KB1 * 64);
         const half_t* sV = sK + KB1 * 64;

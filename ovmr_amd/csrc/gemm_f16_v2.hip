@@ -89,7 +89,8 @@ __global__ __launch_bounds__(512) void gemm_f16_v2_kernel(GemmArgs a, int tiles_
 
     stage(0, 0);
     for (int kt = 0; kt < nk; ++kt) {
-        __syncthreads();                              // vmcnt(0) + barrier: tile kt landed, buffer (kt+1)&1 is free
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // own LDS-DMA retired before the barrier, explicitly
+        __syncthreads();                              // tile kt landed for all waves, buffer (kt+1)&1 is free
         if (kt + 1 < nk && PIPE != 2) stage((kt + 1) & 1, kt + 1);   // PIPE 2/3: timing-only ablations (tools/gemm_bench.py)
         const char* cur = smem + (kt & 1) * STAGE;
         if (PIPE != 1) {
