@@ -34,6 +34,8 @@ struct GemmArgs {
     int epi;
     int rows_in, rows_out;      // EPI_PATCH: patches per image (G*G) and tokens per image (G*G+1)
     float scale;                // EPI_SCALE
+    int n_group;                // N tiles per L2 group (tile order, set by the launcher; 0 = all)
+    int a_blocked, w_blocked;   // operand stored as [rows/128][K/64][128][64] (16 KiB contiguous per (row block, K-tile))
 };
 
 __device__ __forceinline__ float quick_gelu_h(float u) {

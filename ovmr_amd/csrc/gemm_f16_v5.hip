@@ -14,6 +14,7 @@
 //  was measured 5-20 % SLOWER than no prefetch and removed: profiles/r01c_gemm_bench.log, variants 5/7.)
 #include "common.h"
 
+#include <algorithm>
 #include <cstdlib>
 
 namespace {
@@ -28,7 +29,7 @@ __global__ __launch_bounds__(512) void gemm_f16_v5_kernel(GemmArgs a, int tiles_
     constexpr int A_BYTES = BM * 128, STAGE = (BM + BN5) * 128;
     constexpr int AJ = BM / 64;
     constexpr int EP = 144;                            // epilogue LDS row pitch (64 halves + 16 B pad)
-    constexpr bool STAGGER = OPT & 1, BUF = OPT & 2;
+    constexpr bool STAGGER = OPT & 1, BUF = OPT & 2, PRIO = OPT & 4, NOLOAD = OPT & 16;   // NOLOAD: timing-only ablation
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -41,7 +42,25 @@ __global__ __launch_bounds__(512) void gemm_f16_v5_kernel(GemmArgs a, int tiles_
         const int xcd = bid & 7, idx = bid >> 3, q = nwg >> 3, r = nwg & 7;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
-    const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
+    // Tile order inside the XCD's contiguous id range: N tiles in groups of G, M fastest-but-one.  A group's W panels
+    // (G x 256 x K x 2 bytes, kept <= ~2.5 MB by the launcher) then stay in the XCD's 4 MiB L2 while the M panels
+    // stream past; with plain row-major order every tile re-read its W panel from beyond L2 (FETCH_SIZE 8.6x the
+    // algorithmic bytes on c_fc, profiles/r01d_pmc_gemm_v6.json).
+    int tm, tn;
+    {
+        const int G = a.n_group > 0 ? a.n_group : tiles_n;
+        const int full = tiles_n / G, per = tiles_m * G;
+        const int g = bid / per;
+        if (g < full) {
+            const int r = bid - g * per;
+            tm = r / G;
+            tn = g * G + (r - tm * G);
+        } else {
+            const int Gl = tiles_n - full * G, r = bid - full * per;
+            tm = r / Gl;
+            tn = full * G + (r - tm * Gl);
+        }
+    }
     const int m0 = tm * BM, n0 = tn * BN5;
 
     const half_t* A = (const half_t*)a.A;
@@ -51,12 +70,24 @@ __global__ __launch_bounds__(512) void gemm_f16_v5_kernel(GemmArgs a, int tiles_
     const int srow = lane >> 3, slot = lane & 7;
     const int schunk = (slot ^ srow) * 8;
     unsigned oa[AJ], ob[4];                            // byte offsets of this lane's source rows
+    const int nkt = a.K / BK5;
+    // row-major: row * ld * 2 + chunk, K-tile step 128 B.  blocked [rows/128][K/64][128][64]: one (row block, K-tile)
+    // is 16 KiB contiguous, so every LDS-DMA instruction reads 1 KiB of consecutive addresses
+    auto src_off = [&](int row, int ld, int blocked) -> unsigned {
+        return blocked ? (unsigned)(((long)(row >> 7) * nkt) * 16384 + (row & 127) * 128 + schunk * 2)
+                       : (unsigned)(((long)row * ld + schunk) * 2);
+    };
+    const int a_step = a.a_blocked ? 16384 : 128, w_step = a.w_blocked ? 16384 : 128;
 #pragma unroll
-    for (int j = 0; j < AJ; ++j)
-        oa[j] = (unsigned)(((long)min(m0 + wave * (BM / 8) + j * 8 + srow, a.M - 1) * a.lda + schunk) * 2);
+    for (int j = 0; j < AJ; ++j) {
+        const int r = m0 + wave * (BM / 8) + j * 8 + srow;
+        oa[j] = src_off(a.a_blocked ? r : min(r, a.M - 1), a.lda, a.a_blocked);
+    }
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
-        ob[j] = (unsigned)(((long)min(n0 + wave * 32 + j * 8 + srow, a.N - 1) * a.ldw + schunk) * 2);
+    for (int j = 0; j < 4; ++j) {
+        const int r = n0 + wave * 32 + j * 8 + srow;
+        ob[j] = src_off(a.w_blocked ? r : min(r, a.N - 1), a.ldw, a.w_blocked);
+    }
     const int ldsA_w = wave * (BM / 8) * 128;
     const int ldsB_w = A_BYTES + wave * 32 * 128;
 #if defined(__HIP_DEVICE_COMPILE__)   // the buffer-resource type does not exist in the host pass of this TU
@@ -70,18 +101,18 @@ __global__ __launch_bounds__(512) void gemm_f16_v5_kernel(GemmArgs a, int tiles_
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
             for (int j = 0; j < AJ; ++j)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lptr_t)(base + ldsA_w + j * 1024), 16, oa[j], kt * (BK5 * 2), 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lptr_t)(base + ldsA_w + j * 1024), 16, oa[j], kt * a_step, 0, 0);
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lptr_t)(base + ldsB_w + j * 1024), 16, ob[j], kt * (BK5 * 2), 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lptr_t)(base + ldsB_w + j * 1024), 16, ob[j], kt * w_step, 0, 0);
 #endif
         } else {
 #pragma unroll
             for (int j = 0; j < AJ; ++j)
-                __builtin_amdgcn_global_load_lds((gptr_t)((const char*)A + oa[j] + (long)kt * (BK5 * 2)), (lptr_t)(base + ldsA_w + j * 1024), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((gptr_t)((const char*)A + oa[j] + (long)kt * a_step), (lptr_t)(base + ldsA_w + j * 1024), 16, 0, 0);
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                __builtin_amdgcn_global_load_lds((gptr_t)((const char*)W + ob[j] + (long)kt * (BK5 * 2)), (lptr_t)(base + ldsB_w + j * 1024), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((gptr_t)((const char*)W + ob[j] + (long)kt * w_step), (lptr_t)(base + ldsB_w + j * 1024), 16, 0, 0);
         }
     };
 
@@ -95,7 +126,7 @@ __global__ __launch_bounds__(512) void gemm_f16_v5_kernel(GemmArgs a, int tiles_
     const int a_row_off = (wm * (BM / 2) + fr) * 128;
     const int b_row_off = A_BYTES + (wn * 64 + fr) * 128;
     const int ch0 = ((fg) ^ (fr & 7)) << 4, ch1 = ((4 + fg) ^ (fr & 7)) << 4;
-    const int nk = a.K / BK5;
+    const int nk = nkt;
     const bool late = STAGGER && wave >= 4;            // wave-uniform (readfirstlane above)
 
     stage(0, 0);
@@ -104,7 +135,7 @@ __global__ __launch_bounds__(512) void gemm_f16_v5_kernel(GemmArgs a, int tiles_
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                  // tile kt landed for every wave; buffer (kt+1)&1 is free
         __builtin_amdgcn_sched_barrier(0);
-        if (!late && kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
+        if (!late && kt + 1 < nk && !NOLOAD) stage((kt + 1) & 1, kt + 1);
 
         const char* cur = smem + (kt & 1) * STAGE;
         half8_t fb[2][4], fa[3];
@@ -114,6 +145,7 @@ __global__ __launch_bounds__(512) void gemm_f16_v5_kernel(GemmArgs a, int tiles_
         for (int t = 0; t < 4; ++t) fb[0][t] = *(const half8_t*)(cur + b_row_off + t * 2048 + ch0);
         fa[0] = *(const half8_t*)(cur + a_row_off + ch0);
         fa[1] = *(const half8_t*)(cur + a_row_off + 2048 + ch0);
+        if (PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int st = 0; st < MT; ++st) {
             const int nx = st + 2;
@@ -133,7 +165,7 @@ __global__ __launch_bounds__(512) void gemm_f16_v5_kernel(GemmArgs a, int tiles_
             else __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
             __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
         }
-        if (late && kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
+        if (late && kt + 1 < nk && !NOLOAD) stage((kt + 1) & 1, kt + 1);
 #pragma unroll
         for (int st = MT; st < 2 * MT; ++st) {
             const int nx = st + 2;
@@ -147,6 +179,7 @@ __global__ __launch_bounds__(512) void gemm_f16_v5_kernel(GemmArgs a, int tiles_
             if (st + 2 < 2 * MT) __builtin_amdgcn_sched_group_barrier(0x100, 1, 1);
             __builtin_amdgcn_sched_group_barrier(0x008, 4, 1);
         }
+        if (PRIO) __builtin_amdgcn_s_setprio(0);
     }
 
     // ---------------------------------------------------------------- epilogue through LDS
@@ -225,7 +258,15 @@ int launch_v5(const GemmArgs& a, hipStream_t s) {
         HIP_CHECK_RET(hipFuncSetAttribute((const void*)gemm_f16_v5_kernel<EPI, MT, OPT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_f16_v5_kernel<EPI, MT, OPT>), dim3(tiles_m * tiles_n), dim3(512), lds, s, a, tiles_m, tiles_n);
+    GemmArgs b = a;
+    if (b.n_group <= 0) {
+        static int force = -1;
+        if (force < 0) { const char* e = getenv("OVMR_N_GROUP"); force = e ? atoi(e) : 0; }
+        // measured (profiles/r01e_gemm_experiments.md): groups of 4-6 raise the L2 hit rate of qkv / c_fc from 65-68 %
+        // to 72-73 % but move the run time by < 2 %, and hurt c_proj; the default therefore stays row-major (G = all)
+        b.n_group = force > 0 ? std::min(force, tiles_n) : tiles_n;
+    }
+    hipLaunchKernelGGL((gemm_f16_v5_kernel<EPI, MT, OPT>), dim3(tiles_m * tiles_n), dim3(512), lds, s, b, tiles_m, tiles_n);
     return (int)hipGetLastError();
 }
 
@@ -270,6 +311,9 @@ int launch_gemm_f16_v5(const GemmArgs& a, int variant, hipStream_t s) {
         case 8: return dispatch_v5<1>(a, s);
         case 9: return dispatch_v5<2>(a, s);
         case 10: return dispatch_v5<3>(a, s);
+        case 14: return pick_v5<EPI_BIAS, 16>(a, s);       // timing-only: no loads after the first K-tile
+        case 15: return pick_v5<EPI_BIAS, 20>(a, s);       // timing-only: no loads + setprio
+        case 16: return dispatch_v5<4>(a, s);               // setprio(1) around the MFMA stream
         default: return dispatch_v5<0>(a, s);
     }
 }

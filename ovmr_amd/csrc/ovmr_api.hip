@@ -607,6 +607,10 @@ int ovmr_debug_gemm(int f32, int variant, const void* A, const void* W, const vo
         a.lda = K + atoi(e);
         a.ldw = K + atoi(e);
     }
+    if (const char* e = getenv("OVMR_DEBUG_BLOCKED")) {   // timing-only layout experiment (operands are random anyway)
+        a.a_blocked = atoi(e) & 1;
+        a.w_blocked = (atoi(e) >> 1) & 1;
+    }
     a.pos = pos; a.scale = scale; a.rows_in = rows_in; a.rows_out = rows_out;
     return f32 ? launch_gemm_f32(a, (hipStream_t)stream) : launch_gemm_f16(a, variant, (hipStream_t)stream);
 }

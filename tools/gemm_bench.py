@@ -35,8 +35,8 @@ def main():
     out = {}
     for name, m, n, k, epi in shapes:
         g = torch.Generator(device=dev).manual_seed(1)
-        A = (torch.randn((m, k + args.ldpad), generator=g, device=dev) * 0.5).half()
-        W = (torch.randn((n, k + args.ldpad), generator=g, device=dev) * k ** -0.5).half()
+        A = (torch.randn((m + 256, k + args.ldpad), generator=g, device=dev) * 0.5).half()   # slack rows: blocked-layout experiment
+        W = (torch.randn((n + 256, k + args.ldpad), generator=g, device=dev) * k ** -0.5).half()
         b = (torch.randn((n,), generator=g, device=dev) * 0.1).half()
         C = torch.zeros((m, n), dtype=torch.float16, device=dev)
         res = {}
