@@ -1,0 +1,75 @@
+"""Checkpoint ingestion for the hot path (SURVEY.md sections 5.4 and 8f-3).
+
+* CLIP weights: OpenAI's `.pt` files are TorchScript archives; the reference loads them with torch.jit.load and
+  falls back to a plain state dict (trainers/mm_classifier_one_prompt.py:29-44, clip/clip.py:117-129).
+* Prompt-learner weights: Dassl's save_checkpoint layout `<dir>/prompt_learner/model.pth.tar-<epoch>` =
+  {"state_dict", "epoch", "optimizer", "scheduler", "val_result"} plus a `checkpoint` pointer file
+  (Dassl.pytorch/dassl/utils/torchtools.py:27-74); MM_CLS_OP.load_model drops token_prefix / token_suffix and
+  loads with strict=False (trainers/mm_classifier_one_prompt.py:461-493).
+"""
+from __future__ import annotations
+
+import os
+import os.path as osp
+from collections import OrderedDict
+from typing import Dict, Optional
+
+import torch
+
+
+def load_clip_state_dict(path: str) -> Dict[str, torch.Tensor]:
+    """State dict of a CLIP checkpoint: TorchScript archive first, plain torch.save second."""
+    if not osp.exists(path):
+        raise FileNotFoundError(f'CLIP weights not found at "{path}"')
+    try:
+        sd = torch.jit.load(path, map_location="cpu").eval().state_dict()
+    except RuntimeError:
+        sd = torch.load(path, map_location="cpu")
+        if isinstance(sd, dict) and "state_dict" in sd:
+            sd = sd["state_dict"]
+    return {k: v for k, v in sd.items() if k not in ("input_resolution", "context_length", "vocab_size")}   # clip/model.py:930-932
+
+
+def prompt_learner_checkpoint_path(directory: str, epoch: Optional[int] = None, name: str = "prompt_learner") -> str:
+    """`<directory>/<name>/model.pth.tar-<epoch>`; without an epoch: "model-best.pth.tar" like the reference (:470-473),
+    then the `checkpoint` pointer file written by save_checkpoint."""
+    base = osp.join(directory, name)
+    if epoch is not None:
+        return osp.join(base, f"model.pth.tar-{epoch}")
+    best = osp.join(base, "model-best.pth.tar")
+    if osp.exists(best):
+        return best
+    pointer = osp.join(base, "checkpoint")
+    if osp.exists(pointer):
+        with open(pointer) as f:
+            return osp.join(base, f.readline().strip())
+    return best
+
+
+def load_prompt_learner_state(directory: str, epoch: Optional[int] = None) -> Dict[str, torch.Tensor]:
+    path = prompt_learner_checkpoint_path(directory, epoch)
+    if not osp.exists(path):
+        raise FileNotFoundError('Model not found at "{}"'.format(path))          # same message as :477-478
+    ckpt = torch.load(path, map_location="cpu", weights_only=False)
+    sd = ckpt["state_dict"] if "state_dict" in ckpt else ckpt
+    out = OrderedDict()
+    for k, v in sd.items():
+        if k.startswith("module."):                                               # torchtools.py:55-60
+            k = k[len("module."):]
+        if k in ("token_prefix", "token_suffix"):                                 # :482-487
+            continue
+        out[k] = v
+    return out
+
+
+def save_prompt_learner_state(state_dict: Dict[str, torch.Tensor], directory: str, epoch: int,
+                              name: str = "prompt_learner") -> str:
+    """Writes the Dassl layout (used by tests and by users exporting synthetic weights)."""
+    base = osp.join(directory, name)
+    os.makedirs(base, exist_ok=True)
+    fpath = osp.join(base, f"model.pth.tar-{epoch}")
+    torch.save({"state_dict": OrderedDict(state_dict), "epoch": epoch, "optimizer": None, "scheduler": None,
+                "val_result": None}, fpath)
+    with open(osp.join(base, "checkpoint"), "w") as f:
+        f.write(osp.basename(fpath) + "\n")
+    return fpath

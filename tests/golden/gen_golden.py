@@ -214,7 +214,13 @@ def gen_l2(ref_model, ref_clip, ref_l2, spec, seed, n_ctx, shots, tau, classes_p
 
 
 def gen_tokenizer(ref_clip, out):
-    names = ["a .", "a accordion.", "a bass guitar.", "a sea horse.", "a photo of a yin yang."]
+    names = ["a .", "a accordion.", "a bass guitar.", "a sea horse.", "a photo of a yin yang.",
+             "a great white shark.", "a toilet tissue.", "a hen-of-the-woods.", "a jack-o'-lantern.", "a T-shirt.",
+             "a photo of a Boeing 737-800, a type of aircraft.", "a centered satellite photo of annual crop land.",
+             "a photo of a person doing Apply_Eye_Makeup.".replace("_", " "), "a café au lait.", "a 3D printer's nozzle!!",
+             "a   tab\tand  spaces .", "a &amp; b &lt;tag&gt;.", "a don't we'll they're I'm he'd.", "a naïve façade — déjà vu.",
+             "a 日本語 テスト.", "a photo of 12345 67 8.", "a #hashtag @user $100 50%.", "a pneumonoultramicroscopicsilicovolcanoconiosis.",
+             "a MiXeD CaSe StRiNg.", "a (parenthesised) [bracketed] {braced}."]
     out["tok_texts"] = np.array(names)
     out["tok_ids"] = torch.cat([ref_clip.tokenize(t) for t in names]).numpy()
 

@@ -274,3 +274,52 @@ def test_full_size_properties():
     assert_cosine(f4.float().cpu().numpy(), f1[:7].float().cpu().numpy(), 1e-6, "sub-batch")
     np.testing.assert_allclose(f1.float().norm(dim=-1).cpu().numpy(), 1.0, atol=2e-3)
     e.finalize(64, 64, 256)
+
+
+def test_cli_generate_and_evaluate_end_to_end(tmp_path, O):
+    """SURVEY 8f-1/2/3/4 together: folder dataset -> PIL test transform -> BPE tokenizer -> checkpoint files ->
+    CustomCLIP on the HIP path -> mm_classifiers.pt + per-class CSVs; classifier rows checked against the oracle."""
+    from PIL import Image
+    from ovmr_amd import checkpoint, cli
+    from ovmr_amd.tokenizer import BPETokenizer
+    from test_next_rows_cpu import make_synthetic_bpe
+    spec, S, C = synth.SPECS["small"], 3, 4
+    rng = np.random.default_rng(3)
+    root = tmp_path / "data"
+    names = ["tench", "gold fish", "sea_horse", "yin yang"]
+    for split, n in (("train", S + 1), ("val", 2)):
+        for c in range(C):
+            d = root / split / f"n{c:02d}"
+            d.mkdir(parents=True)
+            for i in range(n):
+                base = np.full((70, 90, 3), 40 * c + 30, dtype=np.int32) + rng.integers(-25, 25, (70, 90, 3))
+                Image.fromarray(base.clip(0, 255).astype(np.uint8)).save(d / f"{i}.png")
+    (root / "classnames.txt").write_text("".join(f"n{c:02d} {names[c]}\n" for c in range(C)))
+    bpe = str(tmp_path / "bpe.txt.gz")
+    make_synthetic_bpe(bpe)
+    clip_sd = {k: torch.from_numpy(v) for k, v in synth.clip_state_dict(spec, SEED, jitter=True).items()}
+    torch.save(clip_sd, tmp_path / "clip.pt")
+    pl_sd = {k: torch.from_numpy(v) for k, v in synth.prompt_learner_state_dict(spec, 2, SEED, True).items()}
+    checkpoint.save_prompt_learner_state(pl_sd, str(tmp_path / "ckpt"), 30)
+    out = tmp_path / "out"
+    res = cli.main(["--root", str(root), "--clip-weights", str(tmp_path / "clip.pt"), "--bpe-path", bpe, "--eval-only",
+                    "--model-dir", str(tmp_path / "ckpt"), "--load-epoch", "30", "--output-dir", str(out),
+                    "--eval_mode", "fusion", "--eval_tau", "10", "--n_ctx", "2", "DATASET.NUM_SHOTS", str(S),
+                    "TEST.BATCH_SIZE", "6"])
+    assert set(res) == {"accuracy", "error_rate", "macro_f1"} and 0.0 <= res["accuracy"] <= 100.0
+    for f in ("mm_classifiers.pt", "visual_tokens.pt", "acc_per_class.csv", "f1_per_class.csv"):
+        assert (out / f).exists(), f
+    saved = torch.load(out / "mm_classifiers.pt", map_location="cpu")
+    # oracle on the same decoded images / tokens
+    tk = BPETokenizer(bpe)
+    tok = tk.tokenize(["a " + n.replace("_", " ") + "." for n in names])
+    folders, items = cli.list_split(str(root), "train")
+    ex = cli.exemplar_items(items, S)
+    img = torch.stack([cli.test_transform(Image.open(p), spec.image_resolution) for p, _ in ex])
+    lab = torch.tensor([l for _, l in ex])
+    with torch.no_grad():
+        r = O.forward_prompt(img, lab, tok, _oracle_sd(O, "small"), pl_sd, 2, 10.0, 2, "fp16")
+    for k in ("text_classifier", "vision_classifier", "mm_classifier"):
+        assert_cosine(saved[k].numpy(), r[k].numpy(), COS_TOL, k)
+    assert cli.main(["--root", str(root), "--clip-weights", str(tmp_path / "clip.pt"), "--bpe-path", bpe, "--eval-only",
+                     "--output-dir", str(out)]) == {}          # "results exist ... skip this job"

@@ -1,0 +1,130 @@
+"""CPU tests of the rows SURVEY.md section 8f marks "next": tokenizer, checkpoint files, evaluator, runner helpers."""
+import gzip
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import REPO
+from ovmr_amd import synth
+
+REF_BPE = "/root/reference/clip/bpe_simple_vocab_16e6.txt.gz"   # present only in the build container
+
+
+def make_synthetic_bpe(path):
+    """A merge table with the right number of lines (ids stay < 49408); merges are arbitrary but well formed."""
+    from ovmr_amd.tokenizer import N_MERGES, _byte_alphabet
+    al = _byte_alphabet()
+    lines, seen = ["#version: synthetic"], set()
+    i = 0
+    while len(lines) - 1 < N_MERGES:
+        a, b = al[33 + (i % 94)], al[33 + ((i // 94) % 94)] + al[33 + ((i // 8836) % 94)] + "</w>"
+        i += 1
+        if (a, b) in seen:
+            continue
+        seen.add((a, b))
+        lines.append(f"{a} {b}")
+    with gzip.open(path, "wt", encoding="utf-8") as f:
+        f.write("\n".join(lines) + "\n")
+
+
+@pytest.mark.skipif(not os.path.exists(REF_BPE), reason="CLIP merge table only available next to the reference")
+def test_tokenizer_matches_reference_ids(golden):
+    from ovmr_amd.tokenizer import BPETokenizer
+    g = golden("tokenizer")
+    tk = BPETokenizer(REF_BPE)
+    ids = tk.tokenize([str(t) for t in g["tok_texts"]])
+    np.testing.assert_array_equal(ids.numpy(), g["tok_ids"])
+    assert tk.encode("accordion") == [48760] and tk.encode("a") == [synth.TOK_A] and tk.encode(".") == [synth.TOK_DOT]
+    with pytest.raises(RuntimeError, match="too long"):
+        tk.tokenize(["word " * 100])
+    assert int(tk.tokenize(["word " * 100], truncate=True)[0, -1]) == synth.EOT_ID
+
+
+def test_tokenizer_synthetic_table(tmp_path):
+    from ovmr_amd.tokenizer import BPETokenizer
+    p = str(tmp_path / "bpe.txt.gz")
+    make_synthetic_bpe(p)
+    tk = BPETokenizer(p)
+    t = tk.tokenize(["a sea_horse.".replace("_", " "), "a ."])
+    assert t.shape == (2, 77) and int(t[0, 0]) == synth.SOT_ID and int(t.max()) == synth.EOT_ID
+    assert (t[1].argmax() == (t[1] == synth.EOT_ID).nonzero()[0, 0])
+    with pytest.raises(FileNotFoundError):
+        BPETokenizer(str(tmp_path / "missing.gz"))
+
+
+def test_checkpoint_roundtrip(tmp_path):
+    from ovmr_amd import checkpoint
+    spec = synth.SPECS["tiny"]
+    sd = {k: torch.from_numpy(v) for k, v in synth.prompt_learner_state_dict(spec, 2, 3).items()}
+    extra = dict(sd, token_prefix=torch.zeros(1), token_suffix=torch.zeros(1))
+    extra = {"module." + k: v for k, v in extra.items()}               # DataParallel prefix is stripped
+    f = checkpoint.save_prompt_learner_state(extra, str(tmp_path), 30)
+    assert f.endswith("prompt_learner/model.pth.tar-30")
+    assert open(tmp_path / "prompt_learner" / "checkpoint").read().strip() == "model.pth.tar-30"
+    for epoch in (30, None):                                           # explicit epoch / pointer file
+        got = checkpoint.load_prompt_learner_state(str(tmp_path), epoch)
+        assert sorted(got) == sorted(sd) and all(torch.equal(got[k], sd[k]) for k in sd)
+    with pytest.raises(FileNotFoundError, match="Model not found"):
+        checkpoint.load_prompt_learner_state(str(tmp_path), 7)
+    # CLIP weights saved as a plain state dict (the TorchScript branch needs OpenAI's archive)
+    clip_sd = {k: torch.from_numpy(v) for k, v in synth.clip_state_dict(spec, 1).items()}
+    clip_sd["input_resolution"] = torch.tensor(32)
+    torch.save(clip_sd, tmp_path / "clip.pt")
+    got = checkpoint.load_clip_state_dict(str(tmp_path / "clip.pt"))
+    assert "input_resolution" not in got and torch.equal(got["visual.proj"], clip_sd["visual.proj"])
+    from ovmr_amd.modules import infer_spec
+    s = infer_spec(got)
+    assert (s.vision_width, s.vision_layers, s.vision_patch_size, s.image_resolution, s.embed_dim,
+            s.transformer_width, s.transformer_layers) == (128, 2, 16, 32, 128, 128, 2)
+
+
+def test_evaluator_matches_sklearn(tmp_path):
+    from sklearn.metrics import f1_score
+    from ovmr_amd.evaluator import Classification
+    rng = np.random.default_rng(0)
+    C, n = 7, 500
+    gt = rng.integers(0, C - 1, n)                       # class 6 never appears in y_true
+    logits = rng.normal(size=(n, C)).astype(np.float32)
+    logits[np.arange(n), gt] += 1.0
+    ev = Classification(C, device="cpu")
+    for s in range(0, n, 64):
+        ev.process(torch.from_numpy(logits[s:s + 64]), torch.from_numpy(gt[s:s + 64]))
+    res = ev.evaluate(str(tmp_path))
+    pred = logits.argmax(1)
+    assert res["accuracy"] == pytest.approx(100.0 * (pred == gt).mean())
+    assert res["macro_f1"] == pytest.approx(100.0 * f1_score(gt, pred, average="macro", labels=np.unique(gt)))
+    rows = open(tmp_path / "f1_per_class.csv").read().strip().split("\n")
+    assert rows[0] == "Label,F1" and len(rows) == 1 + len(np.unique(gt))
+    per = 100.0 * f1_score(gt, pred, average=None, labels=np.unique(gt))
+    assert float(rows[1].split(",")[1]) == pytest.approx(per[0])
+    assert open(tmp_path / "acc_per_class.csv").readline().strip() == "Label,Acc"
+
+
+def test_runner_helpers(tmp_path):
+    from PIL import Image
+    from ovmr_amd import cli
+    rng = np.random.default_rng(1)
+    for split, n in (("train", 3), ("val", 2)):
+        for folder in ("n02", "n01"):
+            d = tmp_path / split / folder
+            d.mkdir(parents=True)
+            for i in range(n):
+                Image.fromarray(rng.integers(0, 255, (40 + 10 * i, 70, 3), dtype=np.uint8)).save(d / f"im{i}.png")
+    (tmp_path / "classnames.txt").write_text("n01 tench fish\nn02 goldfish\n")
+    folders, items = cli.list_split(str(tmp_path), "train")
+    assert folders == ["n01", "n02"] and [l for _, l in items] == [0, 0, 0, 1, 1, 1]
+    assert cli.read_classnames(str(tmp_path), folders) == ["tench fish", "goldfish"]
+    ex = cli.exemplar_items(items, 2)
+    assert [l for _, l in ex] == [0, 0, 1, 1]
+    with pytest.raises(ValueError):
+        cli.exemplar_items(items, 5)
+    batches = list(cli.FolderLoader(ex, 2, 32))
+    assert len(batches) == 2 and batches[0]["img"].shape == (2, 3, 32, 32) and batches[0]["label"].tolist() == [0, 0]
+    x = cli.test_transform(Image.fromarray(np.full((50, 80, 3), 128, dtype=np.uint8)), 32)
+    expect = (128 / 255.0 - np.array(cli.PIXEL_MEAN)) / np.array(cli.PIXEL_STD)
+    np.testing.assert_allclose(x.mean(dim=(1, 2)).numpy(), expect, atol=1e-5)
+    a = cli.parse(["--root", "r", "--clip-weights", "w.pt", "--eval-only", "--load-epoch", "30", "--eval_tau", "5",
+                   "DATASET.NUM_SHOTS", "8"])
+    assert a.load_epoch == 30 and a.eval_tau == 5.0 and a.opts == ["DATASET.NUM_SHOTS", "8"]
