@@ -323,3 +323,75 @@ def test_cli_generate_and_evaluate_end_to_end(tmp_path, O):
         assert_cosine(saved[k].numpy(), r[k].numpy(), COS_TOL, k)
     assert cli.main(["--root", str(root), "--clip-weights", str(tmp_path / "clip.pt"), "--bpe-path", bpe, "--eval-only",
                      "--output-dir", str(out)]) == {}          # "results exist ... skip this job"
+
+
+def test_config_c2_hundred_classes_eight_shots(O):
+    """BASELINE config 2 shape (100 classes x 8 shots) on the 'small' model, ragged last batch (100 = 3*32 + 4):
+    every classifier row and the fusion weights against the oracle."""
+    from ovmr_amd import modules
+    spec, C, S = synth.SPECS["small"], 100, 8
+    cm = _clip("small")
+    cfg = modules.make_cfg(n_ctx=2, num_shots=S, output_dir="")
+    pl_sd = {k: torch.from_numpy(v) for k, v in synth.prompt_learner_state_dict(spec, 2, SEED, True).items()}
+    tok = torch.from_numpy(synth.class_token_ids(C, seed=99))
+    model = modules.CustomCLIP(cfg, tok, cm, prompt_learner_state=pl_sd, reserve=(64, 64, 256))
+    order = np.random.default_rng(0).permutation(C)
+    labels = np.repeat(order, S)
+    img = torch.from_numpy(synth.images(C * S, spec.image_resolution, 5, labels, 0.7))
+    loader = [{"img": img[s:s + 32 * S], "label": torch.from_numpy(labels[s:s + 32 * S])} for s in range(0, C * S, 32 * S)]
+    mm, v, fw = model.forward_prompt(loader)
+    with torch.no_grad():
+        r = O.forward_prompt(img, torch.from_numpy(labels), tok, _oracle_sd(O, "small"), pl_sd, 2, 10.0, 32, "fp16")
+    assert_cosine(mm.float().cpu().numpy(), r["mm_classifier"].numpy(), COS_TOL, "mm")
+    assert_cosine(v.float().cpu().numpy(), r["vision_classifier"].numpy(), COS_TOL, "vision")
+    assert_cosine(model.zero_shot_classifier.float().cpu().numpy(), r["text_classifier"].numpy(), COS_TOL, "text")
+    assert_cosine(model.visual_tokens.float().cpu().numpy(), r["visual_tokens"].float().numpy(), COS_TOL, "tokens")
+    counts = model.xval_counts.cpu()
+    assert int(counts[:, 1].sum()) == 3 * C * S and fw.shape == (C, 3)
+    np.testing.assert_allclose(fw.sum(-1).cpu().numpy(), 1.0, atol=1e-5)
+    agree = float(((fw.cpu() - r["fusion_weight"]).abs().max(dim=1).values < 1e-4).float().mean())
+    assert agree > 0.8, f"only {agree:.0%} of the fusion-weight rows agree with the oracle"   # near-tie argmax flips allowed
+
+
+def test_config_c4_sixty_four_shots(O):
+    """BASELINE config 4 shape: 64 shots per class -> aggregator sequence n_ctx + 64 = 66 (fp32 path, L <= 128)."""
+    spec, Cb, S = synth.SPECS["small"], 5, 64
+    e = _clip("small").engine(2)
+    g = torch.Generator().manual_seed(4)
+    feats = torch.nn.functional.normalize(torch.randn(Cb, S, spec.embed_dim, generator=g), dim=-1).half()
+    tokens = e.generate_tokens(feats).cpu()
+    pl = {k: torch.from_numpy(v) for k, v in synth.prompt_learner_state_dict(spec, 2, SEED, True).items()}
+    with torch.no_grad():
+        x = torch.cat([pl["cls_token"].unsqueeze(0).repeat(Cb, 1, 1), feats.float()], dim=1)
+        ref = O.transformer(x, pl, "aggregator.resblocks.", spec.embed_dim // 64, None)[:, :2]
+    np.testing.assert_allclose(tokens.numpy(), ref.numpy(), atol=5e-4, rtol=1e-3)
+    from ovmr_amd.runtime import OvmrError
+    with pytest.raises(OvmrError, match="exceeds 128"):
+        e.generate_tokens(torch.zeros(1, 127, spec.embed_dim, dtype=torch.float16))
+
+
+@pytest.mark.timeout(900)
+def test_config_c5_vit_l14_336_encode(O):
+    """BASELINE config 5 architecture (ViT-L/14@336: 24 layers, width 1024, 577 tokens, patch 14 -> K = 588 padded to
+    640, text width 768): image and text features of 2 inputs against the oracle."""
+    from ovmr_amd import modules
+    spec = synth.SPECS["ViT-L/14@336px"]
+    sd_np = synth.clip_state_dict(spec, SEED, jitter=True)
+    cm = modules.CLIPModel({k: torch.from_numpy(v) for k, v in sd_np.items()}, spec)
+    e = cm.engine(2)
+    e.load_state_dict({}, {k: torch.from_numpy(v) for k, v in synth.prompt_learner_state_dict(spec, 2, SEED, True).items()})
+    e._pl_loaded = True
+    e.finalize(8, 8, 8)
+    img = torch.from_numpy(synth.images(2, 336, seed=8))
+    ids = torch.from_numpy(synth.class_token_ids(3, seed=8))
+    f = e.encode_image(img, normalize=True).float().cpu()
+    t = e.encode_text_ids(ids, normalize=1).float().cpu()
+    sd = O.convert_weights(O.to_torch(sd_np), "fp16")
+    torch.set_num_threads(min(32, os.cpu_count()))
+    with torch.no_grad():
+        rf = O.l2_normalize(O.encode_image(img.half(), sd)).float()
+        rt = O.l2_normalize(O.encode_text(ids, sd)).float()
+    assert_cosine(f.numpy(), rf.numpy(), COS_TOL, "ViT-L/14@336 image features")
+    assert_cosine(t.numpy(), rt.numpy(), COS_TOL, "ViT-L text features")
+    del e, cm
+    torch.cuda.empty_cache()
