@@ -279,7 +279,27 @@ def measure_roofline(eng, spec, args, dev):
     achieved = flops / (us * 1e-6) / 1e12
     return {"bound": "mfma", "kernel": f"gemm_f16 variant {args.gemm}, c_fc shape M={M} N={N} K={K} (+bias+QuickGELU)",
             "achieved": round(achieved, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(achieved / 2500.0, 4),
-            "avg_launch_us": round(us, 2), "flops_per_launch": flops, "traffic": None}
+            "avg_launch_us": round(us, 2), "flops_per_launch": flops, **pmc_traffic(args.gemm, M, N, args.batch)}
+
+
+def pmc_traffic(variant, M, N, batch):
+    """HBM bytes per launch of that kernel from the committed PMC summary (tools/pmc_gemm.sh: separate rocprofv3 --pmc
+    passes, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950) -- null when no summary matches."""
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", f"*pmc_gemm_v{variant}.json")), reverse=True):
+        try:
+            d = json.load(open(f))
+            if d.get("batch") != batch:
+                continue
+            for key, c in d["kernels"].items():
+                for bm in (256, 128):
+                    grid = ((M + bm - 1) // bm) * ((N + 255) // 256) * 512
+                    if key.endswith(f"grid={grid}") and "<2," in key and "hbm_bytes_per_launch" in c:
+                        return {"traffic": c["hbm_bytes_per_launch"], "traffic_unit": "bytes/launch",
+                                "traffic_source": os.path.relpath(f, ROOT), "algorithmic_bytes": 2.0 * (M * (N // 4) + N * (N // 4) + M * N)}
+        except Exception:
+            pass
+    return {"traffic": None}
 
 
 def cpu_baseline(spec, sd, pl, tok, args, n_ctx):
