@@ -135,7 +135,7 @@ int launch_gemm_f16(const GemmArgs& a, int variant, hipStream_t s) {
     if (a.M <= 0 || a.N <= 0) return 0;
     if (a.K <= 0 || (a.K % BK) != 0 || (a.lda & 7) || (a.ldw & 7)) return -2;  // caller pads K to 64
     if (variant >= 1) {
-        int rc = variant == 11 ? launch_gemm_f16_v7(a, s) : ((variant >= 5 && variant <= 10) || (variant >= 14 && variant <= 16)) ? launch_gemm_f16_v5(a, variant, s) : variant == 1 ? launch_gemm_f16_v2(a, 0, s) : variant == 4 ? launch_gemm_f16_v2(a, 1, s) : variant >= 12 ? launch_gemm_f16_v2(a, variant - 10, s) : launch_gemm_f16_v3(a, variant, s);
+        int rc = variant == 11 ? launch_gemm_f16_v7(a, s) : ((variant >= 5 && variant <= 10) || (variant >= 14 && variant <= 17)) ? launch_gemm_f16_v5(a, variant, s) : variant == 1 ? launch_gemm_f16_v2(a, 0, s) : variant == 4 ? launch_gemm_f16_v2(a, 1, s) : variant >= 12 ? launch_gemm_f16_v2(a, variant - 10, s) : launch_gemm_f16_v3(a, variant, s);
         if (rc != -100) return rc;   // -100: shape not supported -> fall through to t128
     }
     switch (a.epi) {

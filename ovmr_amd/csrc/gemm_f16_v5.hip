@@ -29,7 +29,7 @@ __global__ __launch_bounds__(512) void gemm_f16_v5_kernel(GemmArgs a, int tiles_
     constexpr int A_BYTES = BM * 128, STAGE = (BM + BN5) * 128;
     constexpr int AJ = BM / 64;
     constexpr int EP = 144;                            // epilogue LDS row pitch (64 halves + 16 B pad)
-    constexpr bool STAGGER = OPT & 1, BUF = OPT & 2, PRIO = OPT & 4, NOLOAD = OPT & 16;   // NOLOAD: timing-only ablation
+    constexpr bool STAGGER = OPT & 1, BUF = OPT & 2, PRIO = OPT & 4, NOLOAD = OPT & 16, NOREAD = OPT & 32;   // NOLOAD: timing-only ablation
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -129,6 +129,7 @@ __global__ __launch_bounds__(512) void gemm_f16_v5_kernel(GemmArgs a, int tiles_
     const int nk = nkt;
     const bool late = STAGGER && wave >= 4;            // wave-uniform (readfirstlane above)
 
+    half8_t nr_a[2][NOREAD ? MT : 1], nr_b[2][NOREAD ? 4 : 1];
     stage(0, 0);
     for (int kt = 0; kt < nk; ++kt) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -138,6 +139,26 @@ __global__ __launch_bounds__(512) void gemm_f16_v5_kernel(GemmArgs a, int tiles_
         if (!late && kt + 1 < nk && !NOLOAD) stage((kt + 1) & 1, kt + 1);
 
         const char* cur = smem + (kt & 1) * STAGE;
+        if (NOREAD) {   // timing-only ablation: LDS-DMA + MFMA, fragments read once (kt == 0) and reused
+            static_assert(!NOREAD || MT <= 8, "");
+            if (kt == 0) {
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) nr_b[ks][t] = *(const half8_t*)(cur + b_row_off + t * 2048 + (ks ? ch1 : ch0));
+#pragma unroll
+                    for (int t = 0; t < MT; ++t) nr_a[ks][t] = *(const half8_t*)(cur + a_row_off + t * 2048 + (ks ? ch1 : ch0));
+                }
+            }
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(nr_b[ks][j], nr_a[ks][i], acc[i][j], 0, 0, 0);
+            continue;
+        }
         half8_t fb[2][4], fa[3];
         // software-pipelined fragment reads: A fragment of step t+2 and the B fragments of the next k-step are
         // issued before the MFMAs of step t; sched_group_barrier pins that order for the machine scheduler
@@ -314,6 +335,7 @@ int launch_gemm_f16_v5(const GemmArgs& a, int variant, hipStream_t s) {
         case 14: return pick_v5<EPI_BIAS, 16>(a, s);       // timing-only: no loads after the first K-tile
         case 15: return pick_v5<EPI_BIAS, 20>(a, s);       // timing-only: no loads + setprio
         case 16: return dispatch_v5<4>(a, s);               // setprio(1) around the MFMA stream
+        case 17: return pick_v5<EPI_BIAS, 32>(a, s);       // timing-only: loads + MFMA, fragment reads always from buffer 0
         default: return dispatch_v5<0>(a, s);
     }
 }

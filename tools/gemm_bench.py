@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--variants", type=int, nargs="+", default=[0, 1])
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--reps", type=int, default=10)
+    ap.add_argument("--zeros", action="store_true", help="zero-filled operands: shows how much of the time is clock/power (cdna guide rule 25)")
     ap.add_argument("--ldpad", type=int, default=0, help="row padding (halves) of A and W: stride experiment")
     args = ap.parse_args()
     if args.ldpad:
@@ -37,6 +38,8 @@ def main():
         g = torch.Generator(device=dev).manual_seed(1)
         A = (torch.randn((m + 256, k + args.ldpad), generator=g, device=dev) * 0.5).half()   # slack rows: blocked-layout experiment
         W = (torch.randn((n + 256, k + args.ldpad), generator=g, device=dev) * k ** -0.5).half()
+        if args.zeros:
+            A.zero_(); W.zero_()
         b = (torch.randn((n,), generator=g, device=dev) * 0.1).half()
         C = torch.zeros((m, n), dtype=torch.float16, device=dev)
         res = {}
