@@ -395,3 +395,29 @@ def test_config_c5_vit_l14_336_encode(O):
     assert_cosine(t.numpy(), rt.numpy(), COS_TOL, "ViT-L text features")
     del e, cm
     torch.cuda.empty_cache()
+
+
+def test_entry_points_are_graph_capturable():
+    """include/ovmr_hip.h promises: no allocation, no host sync inside the compute calls.  Capture encode_image and the
+    fusion head into a HIP graph on a side stream, replay on new data, compare with the eager result."""
+    e = _clip("small").engine(2)
+    spec = synth.SPECS["small"]
+    C, B = 40, 16
+    g = torch.Generator(device="cuda").manual_seed(2)
+    img = torch.randn(B, 3, spec.image_resolution, spec.image_resolution, generator=g, device="cuda").half()
+    clf = [torch.nn.functional.normalize(torch.randn(C, spec.embed_dim, generator=g, device="cuda"), dim=-1).half() for _ in range(3)]
+    w = torch.softmax(torch.randn(C, 3, generator=g, device="cuda"), -1)
+    feats = torch.empty(B, spec.embed_dim, dtype=torch.float16, device="cuda")
+    e.encode_image(img, normalize=True, out=feats)                       # warm-up (lazy module load, attribute setup)
+    e.fused_logits(feats, clf[0], clf[1], clf[2], w, "fusion")
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        e.encode_image(img, normalize=True, out=feats)
+        out = e.fused_logits(feats, clf[0], clf[1], clf[2], w, "fusion")
+    img.copy_(torch.randn(img.shape, generator=g, device="cuda").half())  # new input, same buffers
+    graph.replay()
+    torch.cuda.synchronize()
+    got = out.clone()
+    ref = e.fused_logits(e.encode_image(img, normalize=True), clf[0], clf[1], clf[2], w, "fusion")
+    assert torch.equal(got, ref)
