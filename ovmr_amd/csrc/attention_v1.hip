@@ -94,27 +94,34 @@ __global__ __launch_bounds__(256) void attn_f16_v1(const half_t* __restrict__ qk
                     s[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[u][ks], s[nt], 0, 0, 0);
                 }
             }
+            // raw-score maximum first (masking only in blocks that need it: the last key block, or the diagonal blocks of
+            // the causal case), then p = exp2(fma(s, scale*log2e, -max*scale*log2e)): one VALU op less per element
+            const bool need_mask = (k0 + KB1 > L) || (CAUSAL && k0 + KB1 - 1 > (t0 + wave + 4 * u) * 16);   // wave-uniform
             float mx = -INFINITY;
+            if (need_mask) {
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int key = k0 + nt * 16 + fg * 4 + r;
+                        const bool ok = (key < L) && (!CAUSAL || key <= q);
+                        s[nt][r] = ok ? s[nt][r] : -INFINITY;
+                    }
+            }
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int key = k0 + nt * 16 + fg * 4 + r;
-                    const bool ok = (key < L) && (!CAUSAL || key <= q);
-                    const float v = ok ? s[nt][r] * scale_log2e : -INFINITY;
-                    s[nt][r] = v;
-                    mx = fmaxf(mx, v);
-                }
+                for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[nt][r]);
             mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            const float m_new = fmaxf(m_run[u], mx);
-            const float alpha = exp2f(m_run[u] - m_new);
+            const float m_new = fmaxf(m_run[u], mx * scale_log2e);        // running maximum kept in the scaled domain
+            const float alpha = __builtin_amdgcn_exp2f(m_run[u] - m_new);   // raw v_exp_f32: arguments are <= 0
             float psum = 0.f;
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float p = exp2f(s[nt][r] - m_new);
+                    const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[nt][r], scale_log2e, -m_new));
                     s[nt][r] = p;
                     psum += p;
                 }
