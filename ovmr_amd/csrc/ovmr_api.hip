@@ -33,7 +33,8 @@ struct Block {   // one residual attention block; element type depends on the to
 struct ovmr_handle {
     ovmr_model_desc d;
     std::map<std::string, Buf> w;
-    std::vector<void*> owned;
+    std::vector<void*> owned;     // weight arena (lives until ovmr_destroy)
+    std::vector<void*> derived;   // layouts rebuilt by every ovmr_finalize
     std::string err;
     bool finalized = false;
     int gemm_variant = 6, attn_variant = 1;   // defaults = fastest verified kernels (tools/gemm_bench.py)
@@ -229,6 +230,7 @@ int ovmr_create(const ovmr_model_desc* d, ovmr_handle** out) {
 void ovmr_destroy(ovmr_handle* h) {
     if (!h) return;
     for (void* p : h->owned) (void)hipFree(p);
+    for (void* p : h->derived) (void)hipFree(p);
     if (h->ws) (void)hipFree(h->ws);
     delete h;
 }
@@ -321,13 +323,23 @@ int ovmr_finalize(ovmr_handle* h, int max_images, int max_prompts, int max_class
 #undef BINDF
 
     // derived layouts
-    h->conv_w = (half_t*)dev_alloc(h, W * h->Kpad * 2);
-    h->pos16_vis = (half_t*)dev_alloc(h, (size_t)h->L * W * 2);
-    h->cls_pos16 = (half_t*)dev_alloc(h, W * 2);
-    h->proj_t = (half_t*)dev_alloc(h, E * W * 2);
-    h->pos16_txt = (half_t*)dev_alloc(h, (size_t)d.context_length * T * 2);
-    h->textproj_t = (half_t*)dev_alloc(h, E * T * 2);
-    half_t* cls16 = (half_t*)dev_alloc(h, W * 2);
+    // derived layouts of a previous finalize are dropped first (the stream is idle: every finalize ends with a sync)
+    HIP_CHECK_RET(hipStreamSynchronize(s));
+    for (void* p : h->derived) (void)hipFree(p);
+    h->derived.clear();
+    auto dalloc = [&](size_t bytes) -> void* {
+        void* p = nullptr;
+        if (hipMalloc(&p, bytes ? bytes : 16) != hipSuccess) return nullptr;
+        h->derived.push_back(p);
+        return p;
+    };
+    h->conv_w = (half_t*)dalloc(W * h->Kpad * 2);
+    h->pos16_vis = (half_t*)dalloc((size_t)h->L * W * 2);
+    h->cls_pos16 = (half_t*)dalloc(W * 2);
+    h->proj_t = (half_t*)dalloc(E * W * 2);
+    h->pos16_txt = (half_t*)dalloc((size_t)d.context_length * T * 2);
+    h->textproj_t = (half_t*)dalloc(E * T * 2);
+    half_t* cls16 = (half_t*)dalloc(W * 2);
     if (!h->conv_w || !h->pos16_vis || !h->cls_pos16 || !h->proj_t || !h->pos16_txt || !h->textproj_t || !cls16)
         return fail(h, OVMR_E_NOMEM, "hipMalloc failed for derived weights");
     CK(launch_pad_rows_f16((const half_t*)conv->p, h->conv_w, (int)W, (int)(3 * P * P), h->Kpad, s));
