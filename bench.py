@@ -43,6 +43,8 @@ def parse():
     ap.add_argument("--classes-per-batch", type=int, default=256)
     ap.add_argument("--gemm", type=int, default=int(os.environ.get("OVMR_GEMM", "6")))
     ap.add_argument("--attn", type=int, default=int(os.environ.get("OVMR_ATTN", "1")))
+    ap.add_argument("--ln-fold", type=int, default=int(os.environ.get("OVMR_LN_FOLD", "1")),
+                    help="1: ln_1/ln_2 folded into the consuming GEMM epilogue; 0: separate LayerNorm kernels")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-classes", type=int, default=16)
     return ap.parse_args()
@@ -95,6 +97,7 @@ def main():
     eng = model.engine
     eng.set_option("gemm", args.gemm)
     eng.set_option("attn", args.attn)
+    eng.set_option("ln_fold", args.ln_fold)
 
     # ---- this rank's shard of the job, resident in HBM (N(0,1) images, fp16), seed 1234 + rank
     c0, c1 = shard_range(C, rank, world)
@@ -163,7 +166,7 @@ def main():
             "config": {"workload": f"OVMR classifier generation + fusion inference, {args.model}, {C} classes x {S} shots "
                                    f"({C * S} exemplar images) + {Q} query images, batch {args.batch}, n_ctx 2, tau 10",
                        "parallelism": f"class/query sharding over {world} rank(s); all-gather rows + all-reduce counters",
-                       "gemm_variant": args.gemm, "attn_variant": args.attn,
+                       "gemm_variant": args.gemm, "attn_variant": args.attn, "ln_fold": args.ln_fold,
                        "images_per_step": images_per_step},
             "roofline": roof,
             "cpu_baseline": cpu,
@@ -263,7 +266,13 @@ def measure_roofline(eng, spec, args, dev):
     Cm = torch.empty((M, N), dtype=torch.float16, device=dev)
     p = lambda t: ctypes.c_void_p(t.data_ptr())
     s = lambda: ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-    launch = lambda: lib.ovmr_debug_gemm(0, args.gemm, p(A), p(Wt), p(b), None, None, p(Cm), M, N, K, N, 2, 1.0, 0, 0, s())
+    if args.ln_fold:   # the c_fc launch of the product path: ln_2 folded into the epilogue (csrc/common.h EPI_LN_BIAS_QGELU)
+        lb, lg = torch.zeros(N, device=dev), torch.zeros(N, device=dev)
+        st = torch.zeros((M, K // 256, 2), device=dev)
+        st[:, 0, 1] = float(K)                                     # mean 0, variance 1
+        launch = lambda: lib.ovmr_debug_gemm(0, args.gemm, p(A), p(Wt), p(lb), p(st), p(lg), p(Cm), M, N, K, N, 7, 1.0, 0, 0, s())
+    else:
+        launch = lambda: lib.ovmr_debug_gemm(0, args.gemm, p(A), p(Wt), p(b), None, None, p(Cm), M, N, K, N, 2, 1.0, 0, 0, s())
     for _ in range(5):
         assert launch() == 0
     torch.cuda.synchronize()
@@ -277,12 +286,12 @@ def measure_roofline(eng, spec, args, dev):
     us = e0.elapsed_time(e1) * 1000.0 / reps
     flops = 2.0 * M * N * K
     achieved = flops / (us * 1e-6) / 1e12
-    return {"bound": "mfma", "kernel": f"gemm_f16 variant {args.gemm}, c_fc shape M={M} N={N} K={K} (+bias+QuickGELU)",
+    return {"bound": "mfma", "kernel": f"gemm_f16 variant {args.gemm}, c_fc shape M={M} N={N} K={K} ({'ln_2 fold + ' if args.ln_fold else ''}bias + QuickGELU)",
             "achieved": round(achieved, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(achieved / 2500.0, 4),
-            "avg_launch_us": round(us, 2), "flops_per_launch": flops, **pmc_traffic(args.gemm, M, N, args.batch)}
+            "avg_launch_us": round(us, 2), "flops_per_launch": flops, **pmc_traffic(args.gemm, M, N, args.batch, 7 if args.ln_fold else 2)}
 
 
-def pmc_traffic(variant, M, N, batch):
+def pmc_traffic(variant, M, N, batch, epi=2):
     """HBM bytes per launch of that kernel from the committed PMC summary (tools/pmc_gemm.sh: separate rocprofv3 --pmc
     passes, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950) -- null when no summary matches."""
     import glob
@@ -294,7 +303,7 @@ def pmc_traffic(variant, M, N, batch):
             for key, c in d["kernels"].items():
                 for bm in (256, 128):
                     grid = ((M + bm - 1) // bm) * ((N + 255) // 256) * 512
-                    if key.endswith(f"grid={grid}") and "<2," in key and "hbm_bytes_per_launch" in c:
+                    if key.endswith(f"grid={grid}") and f"<{epi}," in key and "hbm_bytes_per_launch" in c:
                         return {"traffic": c["hbm_bytes_per_launch"], "traffic_unit": "bytes/launch",
                                 "traffic_source": os.path.relpath(f, ROOT), "algorithmic_bytes": 2.0 * (M * (N // 4) + N * (N // 4) + M * N)}
         except Exception:

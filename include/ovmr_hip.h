@@ -62,7 +62,9 @@ void ovmr_destroy(ovmr_handle* h);
 const char* ovmr_last_error(const ovmr_handle* h);
 const char* ovmr_version(void);
 
-/* Kernel-variant switch used by tests/bench to A/B implementations: key in {"gemm","attn"}. */
+/* Kernel-variant switch used by tests/bench to A/B implementations: key in {"gemm","attn","ln_fold"}.
+ * "ln_fold" (default 1): ln_1 / ln_2 of the fp16 towers are folded into the consuming GEMM where the shape allows
+ * (width % 256 == 0 and >= 256 token rows); 0 runs the separate LayerNorm kernel everywhere. */
 int ovmr_set_option(ovmr_handle* h, const char* key, int value);
 
 /* Weight ingestion -- replaces build_model()/convert_weights()/load_state_dict
@@ -148,10 +150,19 @@ double ovmr_flops_per_prompt(const ovmr_handle* h, int seq_len);
 
 /* Unit-test hooks: launch ONE kernel (no handle).  f32 selects the fp32 (aggregator) kernels;
  * `variant` selects the kernel implementation as ovmr_set_option does; `epi` is the epilogue id of
- * ovmr_amd/csrc/common.h.  A [M,K], W [N,K], C [M,ldc]; qkv [B*L, 3*H*64] -> out [B*L, H*64]. */
+ * ovmr_amd/csrc/common.h.  A [M,K], W [N,K], C [M,ldc]; qkv [B*L, 3*H*64] -> out [B*L, H*64].
+ * For the LayerNorm-folding epilogues (epi 6/7) ovmr_debug_gemm reads `bias` as the folded bias fp32 [N], `pos` as the
+ * column sums fp32 [N] and `res` as the row statistics fp32 [M][K/256][2]; with epi 3 a non-NULL `pos` receives the
+ * statistics of the stored rows, fp32 [M][N/256][2]. */
 int ovmr_debug_gemm(int f32, int variant, const void* A, const void* W, const void* bias, const void* res,
                     const void* pos, void* C, int M, int N, int K, int ldc, int epi, float scale,
                     int rows_in, int rows_out, ovmr_stream stream);
+/* kernel-test hook for the LayerNorm-folding GEMM epilogues (ovmr_amd/csrc/common.h, EPI_LN_BIAS):
+ * x1 = h(h(A1 W1^T + b1) + res) [M,D] (skipped when A1 is NULL: x1 is then an input), C2 = h(LN(x1) W2^T + b2) [M,N2],
+ * QuickGELU on top when qgelu != 0.  Mirrors clip/model.py:191-194 (ln_1 + in_proj, ln_2 + c_fc). */
+int ovmr_debug_lnfold(int variant, const void* A1, const void* W1, const void* b1, const void* res, int M, int D, int K1,
+                      const void* W2, const float* gamma, const float* beta, const void* b2, int N2, int qgelu,
+                      void* x1, void* C2, ovmr_stream stream);
 int ovmr_debug_layernorm(int f32, const void* x, void* y, const float* g, const float* b, int rows, int D,
                          long in_stride, ovmr_stream stream);
 int ovmr_debug_attention(int f32, int variant, const void* qkv, void* out, int B, int L, int H, int causal,

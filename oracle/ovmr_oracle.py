@@ -274,6 +274,21 @@ def fusion_weights(eval_feats: Tensor, mm: Tensor, v: Tensor, t: Tensor, logit_s
     return (tau * ce).softmax(dim=-1), ce                                # :273
 
 
+def get_fusion_weight_coop(eval_feats: Tensor, mm: Tensor, v: Tensor, t: Tensor, logit_scale: Tensor):
+    """CustomCLIP.get_fusion_weight of trainers/coop_mm_classifier.py:235-305, after its encode loop: the features are
+    permuted to [S, C, out] (:277), the einsum runs over that layout and the result is permuted back before the row
+    flatten (:285-287), labels are arange(C) repeated S times (:278), F1 per class (:295-301), softmax(10 * F1) (:304)."""
+    C, S, _ = eval_feats.shape
+    feats = eval_feats.permute(1, 0, 2)                                                  # :277
+    labels = torch.arange(C).reshape(-1, 1).repeat(1, S).flatten(0, 1)                   # :278
+    f1s = []
+    for w in (mm, v, t):                                                                 # :285-287
+        lg = (logit_scale * torch.einsum("bmc,pc->bmp", feats, w)).permute(1, 0, 2).flatten(0, 1)
+        f1s.append(multiclass_f1_per_class(lg, labels, C).reshape(C))                   # :295-301
+    ce = torch.cat([f.unsqueeze(-1) for f in f1s], dim=-1).float()                       # :303
+    return (10 * ce).softmax(dim=-1)                                                     # :304
+
+
 def forward_prompt(images_by_class: Tensor, labels: Tensor, tokenized_prompts: Tensor,
                    sd: Dict[str, Tensor], pl: Dict[str, Tensor], n_ctx: int, tau: float,
                    classes_per_batch: int, prec: str = "fp16", text_classifier: Optional[Tensor] = None):

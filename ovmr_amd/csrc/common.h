@@ -21,6 +21,13 @@ enum {
     EPI_BIAS_RES = 3,    // C = h(h(acc+bias) + res)                 x + attn / x + mlp   (clip/model.py:192-193)
     EPI_PATCH = 4,       // C[b*Lout+1+p] = h(h(acc) + pos[1+p])     conv1 + pos add      (clip/model.py:412-416)
     EPI_SCALE = 5,       // C = h(h(acc) * scale)                    logit_scale * einsum (trainers/mm_classifier_one_prompt.py:263)
+    // LayerNorm folded into the consuming nn.Linear (gemm_f16_v5 only).  A holds the RAW residual stream x, W holds
+    // h(gamma (.) W), and the epilogue applies the row statistics:  LN(x) W^T + bias
+    //   = rstd[m] * (acc[m,n] - mean[m] * ln_g[n]) + ln_b[n],  ln_g[n] = sum_k W'[n,k],  ln_b[n] = bias[n] + sum_k beta[k] W[n,k].
+    // The reference rounds LN(x) to fp16 before the GEMM (clip/model.py:153-159); here the rounding sits on gamma (.) W
+    // instead -- same magnitude of error, one full read + write of the activations less per LayerNorm.
+    EPI_LN_BIAS = 6,        // C = h(LN-folded acc)                  ln_1 + in_proj       (clip/model.py:192)
+    EPI_LN_BIAS_QGELU = 7,  // u = h(LN-folded acc); C = u * sigmoid(1.702u)   ln_2 + c_fc + QuickGELU (clip/model.py:193)
 };
 
 struct GemmArgs {
@@ -36,6 +43,13 @@ struct GemmArgs {
     float scale;                // EPI_SCALE
     int n_group;                // N tiles per L2 group (tile order, set by the launcher; 0 = all)
     int a_blocked, w_blocked;   // operand stored as [rows/128][K/64][128][64] (16 KiB contiguous per (row block, K-tile))
+    // LayerNorm folding (see EPI_LN_BIAS).  Row statistics travel as per-row PARTIAL sums [M][slots][2] fp32
+    // (sum, sum of squares), one slot per 256-column tile of the producing GEMM, summed in slot order by the consumer
+    // (deterministic: no atomics).
+    const float* ln_stats; int ln_slots;   // EPI_LN_*: statistics of the A rows over K
+    const float* ln_g; const float* ln_b;  // EPI_LN_*: [N] fp32 each
+    float* stats_out;                      // EPI_BIAS_RES, optional: partial statistics of the stored C rows, [M][N/256][2]
+    int nt_store;                          // v5: 0 = auto (streaming stores when C is much larger than the L2s), 1 = never, 2 = always
 };
 
 __device__ __forceinline__ float quick_gelu_h(float u) {
@@ -68,6 +82,9 @@ int launch_gemm_f16(const GemmArgs& a, int variant, hipStream_t s);
 int launch_gemm_f32(const GemmArgs& a, hipStream_t s);
 int launch_layernorm(const void* x, void* y, const float* g, const float* b, int rows, int D,
                      long in_row_stride, int is_f32, hipStream_t s);
+int launch_row_stats(const half_t* x, float* stats, int rows, int D, int slots, hipStream_t s);
+int launch_fold_ln(const half_t* W, const float* gamma, const float* beta, const half_t* bias, half_t* Wf, float* g, float* b,
+                   int N, int K, hipStream_t s);
 int launch_attention_f16(const half_t* qkv, half_t* out, int B, int L, int H, int causal, int variant, hipStream_t s);
 int launch_attention_f16_q(const half_t* qkv, half_t* out, int B, int L, int Lq, int H, int causal, int variant, hipStream_t s);
 int launch_attention_f32(const float* qkv, float* out, int B, int L, int H, hipStream_t s);

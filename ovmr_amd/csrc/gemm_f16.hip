@@ -134,8 +134,20 @@ int launch_gemm_f16_v7(const GemmArgs& a, hipStream_t s);               // gemm_
 int launch_gemm_f16(const GemmArgs& a, int variant, hipStream_t s) {
     if (a.M <= 0 || a.N <= 0) return 0;
     if (a.K <= 0 || (a.K % BK) != 0 || (a.lda & 7) || (a.ldw & 7)) return -2;  // caller pads K to 64
+    const bool v5_variant = (variant >= 5 && variant <= 7) || variant == 18 || variant == 19;
+    if (a.epi == EPI_LN_BIAS || a.epi == EPI_LN_BIAS_QGELU || a.stats_out) {   // only the v5 kernel folds LayerNorm
+        const int rc = launch_gemm_f16_v5(a, v5_variant ? variant : 6, s);
+        return rc == -100 ? -4 : rc;
+    }
     if (variant >= 1) {
-        int rc = variant == 11 ? launch_gemm_f16_v7(a, s) : ((variant >= 5 && variant <= 10) || (variant >= 14 && variant <= 17)) ? launch_gemm_f16_v5(a, variant, s) : variant == 1 ? launch_gemm_f16_v2(a, 0, s) : variant == 4 ? launch_gemm_f16_v2(a, 1, s) : variant >= 12 ? launch_gemm_f16_v2(a, variant - 10, s) : launch_gemm_f16_v3(a, variant, s);
+        int rc;
+        if (v5_variant) rc = launch_gemm_f16_v5(a, variant, s);
+        else if (variant == 11) rc = launch_gemm_f16_v7(a, s);
+        else if (variant == 1) rc = launch_gemm_f16_v2(a, 0, s);
+        else if (variant == 4) rc = launch_gemm_f16_v2(a, 1, s);
+        else if (variant == 12 || variant == 13) rc = launch_gemm_f16_v2(a, variant - 10, s);   // timing-only ablations
+        else if (variant == 2 || variant == 3) rc = launch_gemm_f16_v3(a, variant, s);
+        else return -5;                                                                           // unknown variant
         if (rc != -100) return rc;   // -100: shape not supported -> fall through to t128
     }
     switch (a.epi) {

@@ -1,17 +1,21 @@
-// fp16 MFMA GEMM, variants 6/8/9/10: the 256(128)x256x64 LDS-DMA kernel of variant 4 with
-//   * EPILOGUE THROUGH LDS (all variants here).  The C^T accumulator layout gives each lane 4 consecutive
-//     columns of 32 different (row, column-tile) pairs: 32 eight-byte stores per lane, each wave instruction
-//     touching 16 rows x 32 B.  Measured 6.5 us per 256x256 tile (profiles/r01c).  Here h(acc + bias)
-//     (+QuickGELU / scale) goes to a per-wave LDS tile and is read back row-major, so residual / positional
-//     rows are LOADED and results STORED as 16 bytes per lane, 8 rows x 128 B (whole cache lines) per wave
-//     instruction: 4x fewer line transactions, 2x fewer store instructions;
-//   * OPT & 1: STAGGER.  After the per-K-tile barrier all 8 waves used to issue their LDS-DMA first (8 x ~100
-//     cycles in which no MFMA issues on any SIMD, both waves of a SIMD being in lockstep).  Waves 4-7 now issue
-//     theirs after the first k-step, so on every SIMD one wave computes while its partner issues loads;
-//   * OPT & 2: BUFFER loads.  buffer_load_dwordx4 ... offen lds with the row offset in a 32-bit VGPR and the
-//     K offset in an SGPR replaces global_load_lds + a 64-bit VALU add per instruction.
-// (An L2-prefetch experiment -- one 4-byte LDS-DMA touch per thread two K-tiles ahead, counted vmcnt(1) --
-//  was measured 5-20 % SLOWER than no prefetch and removed: profiles/r01c_gemm_bench.log, variants 5/7.)
+// fp16 MFMA GEMM, variant 6 (the default): 256(128)x256x64 tiles, both operands streamed into a double-buffered LDS stage by
+// LDS-DMA (global_load_lds, 16 B per lane, XOR-swizzled 128-byte rows), 8 waves as 2 x 4, software-pipelined fragment reads.
+//
+// Epilogue (measured with tools/gemm_bench.py variants 6 / 18 / 19, profiles/r01g_gemm_epilogue.md: with K = 768 the
+// epilogue was 24-44 % of the kernel, the K loop alone runs at 1.1-1.2 PFLOP/s):
+//   * EVERYTHING THE EPILOGUE READS IS STAGED IN LDS AT KERNEL START -- bias (or the LayerNorm-fold column constants) of the
+//     tile's 256 columns and, for the LN-folding epilogues, rstd / -rstd*mean of its rows.  Their global-load latency hides
+//     under the first K-tile's; loading them after the K loop put ~1-2 us of exposed latency in front of every tile's stores;
+//   * results go THROUGH LDS: the C^T accumulator layout gives each lane 4 consecutive columns of 32 (row, column-tile)
+//     pairs; h(acc + bias) (+QuickGELU / scale / LN fold) is written to a per-wave LDS tile and read back row-major, so
+//     residual / positional rows are LOADED and results STORED 16 bytes per lane, 8 rows x 128 B per wave instruction;
+//   * residual rows (EPI_BIAS_RES) are requested before the accumulators are converted, not in front of each store;
+//   * large outputs are stored with the NONTEMPORAL hint (template bit 512): C then stops evicting the A / W panels the
+//     other tiles of the XCD are streaming out of its 4 MiB L2 (qkv 404 -> 368 us, c_fc 587 -> 556 us);
+//   * EPI_BIAS_RES can emit per-row partial (sum, sum of squares) for the LayerNorm that follows (common.h).
+// Measured and removed (profiles/r01e_gemm_experiments.md, r01g): L2 prefetch touches, staggered LDS-DMA issue, buffer_load
+// ... lds, s_setprio around the MFMA stream, a persistent one-workgroup-per-CU tile loop with the next tile's first K-tile
+// prefetched under the epilogue, W fragments straight from global memory, tile-contiguous C stores.
 #include "common.h"
 
 #include <algorithm>
@@ -23,29 +27,33 @@ constexpr int BK5 = 64, BN5 = 256;
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
+// OPT bits: 64 NOSTORE / 128 NOEPI (timing-only ablations, variants 18 / 19), 512 NT (nontemporal C stores)
 template <int EPI, int MT, int OPT>
 __global__ __launch_bounds__(512) void gemm_f16_v5_kernel(GemmArgs a, int tiles_m, int tiles_n) {
     constexpr int BM = MT * 32;
     constexpr int A_BYTES = BM * 128, STAGE = (BM + BN5) * 128;
     constexpr int AJ = BM / 64;
     constexpr int EP = 144;                            // epilogue LDS row pitch (64 halves + 16 B pad)
-    constexpr bool STAGGER = OPT & 1, BUF = OPT & 2, PRIO = OPT & 4, NOLOAD = OPT & 16, NOREAD = OPT & 32;   // NOLOAD: timing-only ablation
+    constexpr bool NOSTORE = OPT & 64, NOEPI = OPT & 128, NT = OPT & 512;
+    constexpr bool LNF = EPI == EPI_LN_BIAS || EPI == EPI_LN_BIAS_QGELU;   // LayerNorm folded into this GEMM (common.h)
+    constexpr bool HAS_BIAS = EPI == EPI_BIAS || EPI == EPI_BIAS_QGELU || EPI == EPI_BIAS_RES;
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    // behind the two K buffers: column constants [2][256] fp32, row constants [2][BM] fp32
+    float* col_c = (float*)(smem + 2 * STAGE);
+    float* row_c = col_c + 2 * BN5;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;
 
+    // block id -> tile.  XCD-aware: ids congruent mod 8 run on one XCD and get a contiguous range of tiles; inside the
+    // range N tiles come in groups of G with M fastest-but-one (a.n_group, see launch_v5).
     const int nwg = tiles_m * tiles_n;
     int bid = blockIdx.x;
     {
         const int xcd = bid & 7, idx = bid >> 3, q = nwg >> 3, r = nwg & 7;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
-    // Tile order inside the XCD's contiguous id range: N tiles in groups of G, M fastest-but-one.  A group's W panels
-    // (G x 256 x K x 2 bytes, kept <= ~2.5 MB by the launcher) then stay in the XCD's 4 MiB L2 while the M panels
-    // stream past; with plain row-major order every tile re-read its W panel from beyond L2 (FETCH_SIZE 8.6x the
-    // algorithmic bytes on c_fc, profiles/r01d_pmc_gemm_v6.json).
     int tm, tn;
     {
         const int G = a.n_group > 0 ? a.n_group : tiles_n;
@@ -70,11 +78,11 @@ __global__ __launch_bounds__(512) void gemm_f16_v5_kernel(GemmArgs a, int tiles_
     const int srow = lane >> 3, slot = lane & 7;
     const int schunk = (slot ^ srow) * 8;
     unsigned oa[AJ], ob[4];                            // byte offsets of this lane's source rows
-    const int nkt = a.K / BK5;
+    const int nk = a.K / BK5;
     // row-major: row * ld * 2 + chunk, K-tile step 128 B.  blocked [rows/128][K/64][128][64]: one (row block, K-tile)
     // is 16 KiB contiguous, so every LDS-DMA instruction reads 1 KiB of consecutive addresses
     auto src_off = [&](int row, int ld, int blocked) -> unsigned {
-        return blocked ? (unsigned)(((long)(row >> 7) * nkt) * 16384 + (row & 127) * 128 + schunk * 2)
+        return blocked ? (unsigned)(((long)(row >> 7) * nk) * 16384 + (row & 127) * 128 + schunk * 2)
                        : (unsigned)(((long)row * ld + schunk) * 2);
     };
     const int a_step = a.a_blocked ? 16384 : 128, w_step = a.w_blocked ? 16384 : 128;
@@ -90,30 +98,15 @@ __global__ __launch_bounds__(512) void gemm_f16_v5_kernel(GemmArgs a, int tiles_
     }
     const int ldsA_w = wave * (BM / 8) * 128;
     const int ldsB_w = A_BYTES + wave * 32 * 128;
-#if defined(__HIP_DEVICE_COMPILE__)   // the buffer-resource type does not exist in the host pass of this TU
-    __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, 0x7fffffff, 0x00020000);
-    __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)W, 0, 0x7fffffff, 0x00020000);
-#endif
 
     auto stage = [&](int buf, int kt) {
         char* base = smem + buf * STAGE;
-        if (BUF) {
-#if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
-            for (int j = 0; j < AJ; ++j)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lptr_t)(base + ldsA_w + j * 1024), 16, oa[j], kt * a_step, 0, 0);
+        for (int j = 0; j < AJ; ++j)
+            __builtin_amdgcn_global_load_lds((gptr_t)((const char*)A + oa[j] + (long)kt * a_step), (lptr_t)(base + ldsA_w + j * 1024), 16, 0, 0);
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lptr_t)(base + ldsB_w + j * 1024), 16, ob[j], kt * w_step, 0, 0);
-#endif
-        } else {
-#pragma unroll
-            for (int j = 0; j < AJ; ++j)
-                __builtin_amdgcn_global_load_lds((gptr_t)((const char*)A + oa[j] + (long)kt * a_step), (lptr_t)(base + ldsA_w + j * 1024), 16, 0, 0);
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                __builtin_amdgcn_global_load_lds((gptr_t)((const char*)W + ob[j] + (long)kt * w_step), (lptr_t)(base + ldsB_w + j * 1024), 16, 0, 0);
-        }
+        for (int j = 0; j < 4; ++j)
+            __builtin_amdgcn_global_load_lds((gptr_t)((const char*)W + ob[j] + (long)kt * w_step), (lptr_t)(base + ldsB_w + j * 1024), 16, 0, 0);
     };
 
     float4_t acc[MT][4];
@@ -126,39 +119,39 @@ __global__ __launch_bounds__(512) void gemm_f16_v5_kernel(GemmArgs a, int tiles_
     const int a_row_off = (wm * (BM / 2) + fr) * 128;
     const int b_row_off = A_BYTES + (wn * 64 + fr) * 128;
     const int ch0 = ((fg) ^ (fr & 7)) << 4, ch1 = ((4 + fg) ^ (fr & 7)) << 4;
-    const int nk = nkt;
-    const bool late = STAGGER && wave >= 4;            // wave-uniform (readfirstlane above)
 
-    half8_t nr_a[2][NOREAD ? MT : 1], nr_b[2][NOREAD ? 4 : 1];
     stage(0, 0);
+
+    // epilogue constants -> LDS, under the latency of the first K-tile (first read after the K loop: many barriers later)
+    if (tid < BN5) {
+        const int n = n0 + tid;
+        float c0 = 0.f, c1 = 0.f;
+        if (n < a.N) {
+            if (HAS_BIAS) c0 = (float)((const half_t*)a.bias)[n];
+            if (LNF) { c0 = a.ln_g[n]; c1 = a.ln_b[n]; }
+        }
+        col_c[tid] = c0;
+        col_c[BN5 + tid] = c1;
+    } else if (LNF && tid - BN5 < BM) {
+        const int r = tid - BN5;
+        const float2_t* sp = (const float2_t*)a.ln_stats + (long)min(m0 + r, a.M - 1) * a.ln_slots;
+        float su = 0.f, sq = 0.f;
+        for (int sl = 0; sl < a.ln_slots; ++sl) { const float2_t p = sp[sl]; su += p[0]; sq += p[1]; }
+        const float inv_k = 1.0f / (float)a.K;
+        const float mean = su * inv_k;
+        const float rstd = 1.0f / sqrtf(fmaxf(sq * inv_k - mean * mean, 0.f) + 1e-5f);
+        row_c[r] = rstd;
+        row_c[BM + r] = -rstd * mean;
+    }
+
     for (int kt = 0; kt < nk; ++kt) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                  // tile kt landed for every wave; buffer (kt+1)&1 is free
         __builtin_amdgcn_sched_barrier(0);
-        if (!late && kt + 1 < nk && !NOLOAD) stage((kt + 1) & 1, kt + 1);
+        if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
 
         const char* cur = smem + (kt & 1) * STAGE;
-        if (NOREAD) {   // timing-only ablation: LDS-DMA + MFMA, fragments read once (kt == 0) and reused
-            static_assert(!NOREAD || MT <= 8, "");
-            if (kt == 0) {
-#pragma unroll
-                for (int ks = 0; ks < 2; ++ks) {
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) nr_b[ks][t] = *(const half8_t*)(cur + b_row_off + t * 2048 + (ks ? ch1 : ch0));
-#pragma unroll
-                    for (int t = 0; t < MT; ++t) nr_a[ks][t] = *(const half8_t*)(cur + a_row_off + t * 2048 + (ks ? ch1 : ch0));
-                }
-            }
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-                for (int i = 0; i < MT; ++i)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(nr_b[ks][j], nr_a[ks][i], acc[i][j], 0, 0, 0);
-            continue;
-        }
         half8_t fb[2][4], fa[3];
         // software-pipelined fragment reads: A fragment of step t+2 and the B fragments of the next k-step are
         // issued before the MFMAs of step t; sched_group_barrier pins that order for the machine scheduler
@@ -166,7 +159,6 @@ __global__ __launch_bounds__(512) void gemm_f16_v5_kernel(GemmArgs a, int tiles_
         for (int t = 0; t < 4; ++t) fb[0][t] = *(const half8_t*)(cur + b_row_off + t * 2048 + ch0);
         fa[0] = *(const half8_t*)(cur + a_row_off + ch0);
         fa[1] = *(const half8_t*)(cur + a_row_off + 2048 + ch0);
-        if (PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int st = 0; st < MT; ++st) {
             const int nx = st + 2;
@@ -186,7 +178,6 @@ __global__ __launch_bounds__(512) void gemm_f16_v5_kernel(GemmArgs a, int tiles_
             else __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
             __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
         }
-        if (late && kt + 1 < nk && !NOLOAD) stage((kt + 1) & 1, kt + 1);
 #pragma unroll
         for (int st = MT; st < 2 * MT; ++st) {
             const int nx = st + 2;
@@ -200,35 +191,63 @@ __global__ __launch_bounds__(512) void gemm_f16_v5_kernel(GemmArgs a, int tiles_
             if (st + 2 < 2 * MT) __builtin_amdgcn_sched_group_barrier(0x100, 1, 1);
             __builtin_amdgcn_sched_group_barrier(0x008, 4, 1);
         }
-        if (PRIO) __builtin_amdgcn_s_setprio(0);
     }
 
     // ---------------------------------------------------------------- epilogue through LDS
     half_t* C = (half_t*)a.C;
+    if (NOEPI) {            // timing-only ablation: the K loop alone (the store below never happens on real data)
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) sum += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+        if (sum == 12345.678f) C[tid] = (half_t)sum;
+        return;
+    }
     char* et = smem + wave * (64 * EP);                 // this wave's 64-row x 64-column staging tile
     const int er = lane >> 3, ec = (lane & 7) * 8;     // phase 2: row within an 8-row group, first column
-    half4_t bias4[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int n = n0 + wn * 64 + j * 16 + fg * 4;
-        bias4[j] = (half4_t){(half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f};
-        if ((EPI == EPI_BIAS || EPI == EPI_BIAS_QGELU || EPI == EPI_BIAS_RES) && n + 3 < a.N)
-            bias4[j] = *(const half4_t*)((const half_t*)a.bias + n);
-    }
+    const bool emit_stats = EPI == EPI_BIAS_RES && a.stats_out != nullptr;
+    float* stat_lds = (float*)(smem + 8 * 64 * EP);      // [BM rows][4 column waves][2], behind the staging tiles
 #pragma unroll
     for (int h = 0; h < MT / 4; ++h) {
         __syncthreads();                                // main-loop reads / previous half's reads are done
+        // residual rows of this half: requested now, consumed after phase 1 (their latency used to sit in front of every
+        // store: ~6 us per 256x256 tile on out_proj / c_proj)
+        half8_t res8[EPI == EPI_BIAS_RES ? 8 : 1];
+        if (EPI == EPI_BIAS_RES) {
+            const int nn = n0 + wn * 64 + ec;
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+            for (int it = 0; it < 8; ++it) {
+                const int m = min(m0 + wm * (BM / 2) + h * 64 + it * 8 + er, a.M - 1);
+                res8[EPI == EPI_BIAS_RES ? it : 0] = *(const half8_t*)((const half_t*)a.res + (long)m * a.ldres + min(nn, a.N - 8));
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float ln_r = 0.f, ln_t = 0.f;               // LNF: rstd and -rstd * mean of this lane's row
+            if (LNF) {
+                const int r = wm * (BM / 2) + h * 64 + i * 16 + fr;
+                ln_r = row_c[r];
+                ln_t = row_c[BM + r];
+            }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                float4_t v = acc[h * 4 + i][j];
+                const float4_t v = acc[h * 4 + i][j];
+                const int cc = wn * 64 + j * 16 + fg * 4;
+                const float4_t c0 = *(const float4_t*)(col_c + cc);
                 half4_t o;
-                if (EPI == EPI_BIAS || EPI == EPI_BIAS_QGELU || EPI == EPI_BIAS_RES) {
-                    const half4_t b4 = bias4[j];
+                if (LNF) {
+                    const float4_t c1 = *(const float4_t*)(col_c + BN5 + cc);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        float x = (float)(half_t)(v[r] + (float)b4[r]);
+                        float x = (float)(half_t)fmaf(ln_r, v[r], fmaf(ln_t, c0[r], c1[r]));
+                        if (EPI == EPI_LN_BIAS_QGELU) x = quick_gelu_h(x);
+                        o[r] = (half_t)x;
+                    }
+                } else if (HAS_BIAS) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float x = (float)(half_t)(v[r] + c0[r]);
                         if (EPI == EPI_BIAS_QGELU) x = quick_gelu_h(x);
                         o[r] = (half_t)x;
                     }
@@ -242,6 +261,7 @@ __global__ __launch_bounds__(512) void gemm_f16_v5_kernel(GemmArgs a, int tiles_
                 }
                 *(half4_t*)(et + (i * 16 + fr) * EP + (j * 16 + fg * 4) * 2) = o;
             }
+        }
         __syncthreads();
         const int nn = n0 + wn * 64 + ec;
 #pragma unroll
@@ -252,9 +272,18 @@ __global__ __launch_bounds__(512) void gemm_f16_v5_kernel(GemmArgs a, int tiles_
                 half8_t v = *(const half8_t*)(et + row * EP + ec * 2);
                 long crow = m;
                 if (EPI == EPI_BIAS_RES) {
-                    half8_t r8 = *(const half8_t*)((const half_t*)a.res + (long)m * a.ldres + nn);
+                    const half8_t r8 = res8[EPI == EPI_BIAS_RES ? it : 0];
 #pragma unroll
                     for (int k = 0; k < 8; ++k) v[k] = (half_t)((float)v[k] + (float)r8[k]);
+                    if (emit_stats) {                   // statistics of the STORED fp16 row slice (8 lanes share a row)
+                        float su = 0.f, sq = 0.f;
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) { const float f = (float)v[k]; su += f; sq = fmaf(f, f, sq); }
+#pragma unroll
+                        for (int o = 1; o < 8; o <<= 1) { su += __shfl_xor(su, o, 64); sq += __shfl_xor(sq, o, 64); }
+                        if ((lane & 7) == 0)
+                            *(float2_t*)(stat_lds + ((wm * (BM / 2) + h * 64 + row) * 4 + wn) * 2) = (float2_t){su, sq};
+                    }
                 }
                 if (EPI == EPI_PATCH) {
                     const int b = m / a.rows_in, p = m - b * a.rows_in;
@@ -263,22 +292,39 @@ __global__ __launch_bounds__(512) void gemm_f16_v5_kernel(GemmArgs a, int tiles_
 #pragma unroll
                     for (int k = 0; k < 8; ++k) v[k] = (half_t)((float)v[k] + (float)p8[k]);
                 }
-                *(half8_t*)(C + crow * a.ldc + nn) = v;
+                half8_t* dst = (half8_t*)(C + crow * a.ldc + nn);
+                if (NT) __builtin_nontemporal_store(v, dst);
+                else if (!NOSTORE || (float)v[0] == 12345.678f) *dst = v;   // NOSTORE: timing-only ablation
             }
         }
     }
+    if (emit_stats) {       // one (sum, sum of squares) pair per row and N tile, the four column waves added in fixed order
+        __syncthreads();
+        if (tid < BM && m0 + tid < a.M) {
+            const float* p = stat_lds + tid * 8;
+            const float su = ((p[0] + p[2]) + p[4]) + p[6], sq = ((p[1] + p[3]) + p[5]) + p[7];
+            *(float2_t*)(a.stats_out + ((long)(m0 + tid) * tiles_n + tn) * 2) = (float2_t){su, sq};
+        }
+    }
+}
+
+template <int EPI, int MT, int OPT>
+int launch_v5_k(const GemmArgs& b, int tiles_m, int tiles_n, hipStream_t s) {
+    constexpr int BM = MT * 32;
+    const size_t lds = (size_t)2 * (BM + BN5) * 128 + 2 * BN5 * 4 + 2 * BM * 4;
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIP_CHECK_RET(hipFuncSetAttribute((const void*)gemm_f16_v5_kernel<EPI, MT, OPT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm_f16_v5_kernel<EPI, MT, OPT>), dim3(tiles_m * tiles_n), dim3(512), lds, s, b, tiles_m, tiles_n);
+    return (int)hipGetLastError();
 }
 
 template <int EPI, int MT, int OPT>
 int launch_v5(const GemmArgs& a, hipStream_t s) {
     constexpr int BM = MT * 32;
     const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + BN5 - 1) / BN5;
-    const size_t lds = (size_t)2 * (BM + BN5) * 128;
-    static bool attr_set = false;
-    if (!attr_set) {
-        HIP_CHECK_RET(hipFuncSetAttribute((const void*)gemm_f16_v5_kernel<EPI, MT, OPT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
     GemmArgs b = a;
     if (b.n_group <= 0) {
         static int force = -1;
@@ -287,8 +333,18 @@ int launch_v5(const GemmArgs& a, hipStream_t s) {
         // to 72-73 % but move the run time by < 2 %, and hurt c_proj; the default therefore stays row-major (G = all)
         b.n_group = force > 0 ? std::min(force, tiles_n) : tiles_n;
     }
-    hipLaunchKernelGGL((gemm_f16_v5_kernel<EPI, MT, OPT>), dim3(tiles_m * tiles_n), dim3(512), lds, s, b, tiles_m, tiles_n);
-    return (int)hipGetLastError();
+    if (b.nt_store == 0) {
+        // C written with the nontemporal hint does not evict the A / W panels the other tiles of the XCD are streaming from
+        // its 4 MiB L2 (profiles/r01g_gemm_epilogue.md).  Not for the in-place residual updates (out_proj / c_proj: +4 %
+        // slower) nor for small outputs the next kernel reads straight back (logits for the argmax).  The hint has to be
+        // a template parameter: a run-time branch around two stores of the same value is merged by the compiler, which
+        // drops the hint.
+        static int force = -1;
+        if (force < 0) { const char* e = getenv("OVMR_NT_STORE"); force = e ? atoi(e) : 0; }
+        b.nt_store = force ? force : (b.epi != EPI_BIAS_RES && (size_t)b.M * b.N * 2 >= ((size_t)48 << 20) ? 2 : 1);
+    }
+    if (OPT == 0 && b.nt_store == 2) return launch_v5_k<EPI, MT, 512>(b, tiles_m, tiles_n, s);
+    return launch_v5_k<EPI, MT, OPT>(b, tiles_m, tiles_n, s);
 }
 
 int g_force_mt = -1;   // debug: OVMR_FORCE_MT=4|8 pins the M tile (tools/gemm_bench.py)
@@ -316,26 +372,26 @@ int dispatch_v5(const GemmArgs& a, hipStream_t s) {
         case EPI_BIAS_RES: return pick_v5<EPI_BIAS_RES, OPT>(a, s);
         case EPI_PATCH: return pick_v5<EPI_PATCH, OPT>(a, s);
         case EPI_SCALE: return pick_v5<EPI_SCALE, OPT>(a, s);
+        case EPI_LN_BIAS: return pick_v5<EPI_LN_BIAS, OPT>(a, s);
+        case EPI_LN_BIAS_QGELU: return pick_v5<EPI_LN_BIAS_QGELU, OPT>(a, s);
     }
     return -3;
 }
 
 }  // namespace
 
-// variant 6: LDS epilogue only; 8: + stagger; 9: + buffer loads; 10: + both
+// variant 6: the default; 18 / 19: timing-only epilogue ablations (no global stores / no epilogue at all)
 int launch_gemm_f16_v5(const GemmArgs& a, int variant, hipStream_t s) {
     if (a.M < 256 || a.N < 128 || (a.N & 7) || (a.ldc & 7) || (a.epi == EPI_BIAS_RES && (a.ldres & 7)) ||
         ((uintptr_t)a.C & 15) || (a.epi == EPI_BIAS_RES && ((uintptr_t)a.res & 15)) ||
         (long)a.M * a.lda * 2 >= 0x7fffffffL || (long)a.N * a.ldw * 2 >= 0x7fffffffL)
         return -100;
+    const bool lnf = a.epi == EPI_LN_BIAS || a.epi == EPI_LN_BIAS_QGELU;
+    if (lnf && ((a.N & 63) || !a.ln_stats || a.ln_slots < 1 || !a.ln_g || !a.ln_b)) return -2;
+    if (a.stats_out && (a.epi != EPI_BIAS_RES || (a.N & 255))) return -2;
     switch (variant) {
-        case 8: return dispatch_v5<1>(a, s);
-        case 9: return dispatch_v5<2>(a, s);
-        case 10: return dispatch_v5<3>(a, s);
-        case 14: return pick_v5<EPI_BIAS, 16>(a, s);       // timing-only: no loads after the first K-tile
-        case 15: return pick_v5<EPI_BIAS, 20>(a, s);       // timing-only: no loads + setprio
-        case 16: return dispatch_v5<4>(a, s);               // setprio(1) around the MFMA stream
-        case 17: return pick_v5<EPI_BIAS, 32>(a, s);       // timing-only: loads + MFMA, fragment reads always from buffer 0
+        case 18: return a.epi == EPI_BIAS_QGELU ? pick_v5<EPI_BIAS_QGELU, 64>(a, s) : pick_v5<EPI_BIAS, 64>(a, s);
+        case 19: return pick_v5<EPI_BIAS, 128>(a, s);
         default: return dispatch_v5<0>(a, s);
     }
 }

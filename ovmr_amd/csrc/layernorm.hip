@@ -69,7 +69,59 @@ __global__ __launch_bounds__(256) void layernorm_rows(const T* __restrict__ x, T
     }
 }
 
+// Partial row statistics of an fp16 matrix in the layout the LN-folding GEMM epilogue consumes (common.h, EPI_LN_BIAS):
+// slot 0 = (sum, sum of squares) of the whole row, the other slots zero.  Used once per tower call, in front of the
+// first block; every later LayerNorm gets its statistics from the EPI_BIAS_RES epilogue that produced its input.
+__global__ __launch_bounds__(256) void row_stats_kernel(const half_t* __restrict__ x, float* __restrict__ stats, int rows, int D, int slots) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const half_t* xr = x + (long)row * D;
+    float s = 0.f, q = 0.f;
+    for (int c = lane * 8; c < D; c += 512) {
+        half8_t h = *(const half8_t*)(xr + c);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { const float v = (float)h[k]; s += v; q += v * v; }
+    }
+    s = wave_sum(s);
+    q = wave_sum(q);
+    if (lane < slots) *(float2_t*)(stats + ((long)row * slots + lane) * 2) = lane == 0 ? (float2_t){s, q} : (float2_t){0.f, 0.f};
+}
+
+// W'[n,k] = h(gamma[k] * W[n,k]);  g[n] = sum_k W'[n,k];  b[n] = bias[n] + sum_k beta[k] * W[n,k]   (one wave per row n)
+__global__ __launch_bounds__(256) void fold_ln_kernel(const half_t* __restrict__ W, const float* __restrict__ gamma,
+                                                      const float* __restrict__ beta, const half_t* __restrict__ bias,
+                                                      half_t* __restrict__ Wf, float* __restrict__ g, float* __restrict__ b, int N, int K) {
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= N) return;
+    float sg = 0.f, sb = 0.f;
+    for (int k = lane; k < K; k += 64) {
+        const float w = (float)W[(long)n * K + k];
+        const half_t wf = (half_t)(gamma[k] * w);
+        Wf[(long)n * K + k] = wf;
+        sg += (float)wf;
+        sb += beta[k] * w;
+    }
+    sg = wave_sum(sg);
+    sb = wave_sum(sb);
+    if (lane == 0) { g[n] = sg; b[n] = sb + (float)bias[n]; }
+}
+
 }  // namespace
+
+int launch_row_stats(const half_t* x, float* stats, int rows, int D, int slots, hipStream_t s) {
+    if (rows <= 0) return 0;
+    if ((D & 7) || slots < 1 || slots > 64) return -2;
+    hipLaunchKernelGGL(row_stats_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, stats, rows, D, slots);
+    return (int)hipGetLastError();
+}
+
+int launch_fold_ln(const half_t* W, const float* gamma, const float* beta, const half_t* bias, half_t* Wf, float* g, float* b,
+                   int N, int K, hipStream_t s) {
+    hipLaunchKernelGGL(fold_ln_kernel, dim3((N + 3) / 4), dim3(256), 0, s, W, gamma, beta, bias, Wf, g, b, N, K);
+    return (int)hipGetLastError();
+}
 
 int launch_layernorm(const void* x, void* y, const float* g, const float* b, int rows, int D,
                      long in_row_stride, int is_f32, hipStream_t s) {

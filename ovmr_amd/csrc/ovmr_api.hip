@@ -26,6 +26,9 @@ struct Buf {
 struct Block {   // one residual attention block; element type depends on the tower
     void *in_w, *in_b, *out_w, *out_b, *fc_w, *fc_b, *pj_w, *pj_b;
     float *ln1_g, *ln1_b, *ln2_g, *ln2_b;
+    // LayerNorm folded into in_proj / c_fc (common.h EPI_LN_BIAS): h(gamma (.) W), column sums, folded bias; built by finalize
+    half_t *in_wf = nullptr, *fc_wf = nullptr;
+    float *in_g = nullptr, *in_bf = nullptr, *fc_g = nullptr, *fc_bf = nullptr;
 };
 
 }  // namespace
@@ -38,6 +41,7 @@ struct ovmr_handle {
     std::string err;
     bool finalized = false;
     int gemm_variant = 6, attn_variant = 1;   // defaults = fastest verified kernels (tools/gemm_bench.py)
+    int ln_fold = 1;                          // fold ln_1 / ln_2 of the fp16 towers into the consuming GEMM where the shape allows
     float logit_scale_exp = 100.f;
     bool have_logit_scale = false;
 
@@ -106,7 +110,7 @@ const Buf* find(ovmr_handle* h, const std::string& name, size_t elems) {
 }
 
 int bind_blocks(ovmr_handle* h, const std::string& prefix, int layers, int W, std::vector<Block>& out) {
-    out.resize(layers);
+    out.assign(layers, Block());
     const size_t w = (size_t)W;
     for (int i = 0; i < layers; ++i) {
         const std::string p = prefix + std::to_string(i) + ".";
@@ -151,29 +155,54 @@ size_t image_ws_bytes(const ovmr_handle* h, long B) {
     s += align_up((size_t)M * 3 * W * 2);          // qkv
     s += align_up((size_t)M * 4 * W * 2);          // mlp hidden
     s += align_up((size_t)B * W * 2);              // CLS rows
+    s += align_up((size_t)M * ((W + 255) / 256) * 8);   // LayerNorm partial statistics
     return s;
 }
 size_t text_ws_bytes(const ovmr_handle* h, long N) {
     const long M = N * h->d.context_length, W = h->d.transformer_width;
     return align_up((size_t)M * W * 2) * 2 + align_up((size_t)M * 3 * W * 2) + align_up((size_t)M * 4 * W * 2) +
-           align_up((size_t)N * W * 2) + align_up((size_t)N * 4);
+           align_up((size_t)N * W * 2) + align_up((size_t)N * 4) + align_up((size_t)M * ((W + 255) / 256) * 8);
 }
 size_t agg_ws_bytes(const ovmr_handle* h, long rows) {
     const long D = h->d.embed_dim;
     return align_up((size_t)rows * D * 4) * 2 + align_up((size_t)rows * 3 * D * 4) + align_up((size_t)rows * 4 * D * 4);
 }
 
+// LayerNorm folding applies when the v5 GEMM takes the shape (it then also emits the statistics): see common.h.
+bool can_fold_ln(const ovmr_handle* h, const Block& k, int M, int W) {
+    return h->ln_fold && k.in_wf && M >= 256 && (W % 256) == 0 && W / 256 <= 64;
+}
+
+GemmArgs gemm_ln(GemmArgs a, const float* stats, int slots, const float* g, const float* b) {
+    a.ln_stats = stats; a.ln_slots = slots; a.ln_g = g; a.ln_b = b;
+    return a;
+}
+GemmArgs gemm_stats(GemmArgs a, float* stats) {
+    a.stats_out = stats;
+    return a;
+}
+
 // One pre-LN residual attention block (clip/model.py:191-194) on fp16 activations.
+// stats != nullptr: ln_1 / ln_2 are folded into in_proj / c_fc.  On entry `stats` holds the partial row statistics of x
+// (launch_row_stats, or the previous block's c_proj epilogue); on exit those of the new x.
 int run_block_f16(ovmr_handle* h, const Block& k, half_t* x, half_t* y, half_t* qkv, half_t* hid,
-                  int nseq, int L, int W, int causal, hipStream_t s) {
-    const int M = nseq * L, H = W / 64;
-    CK(launch_layernorm(x, y, k.ln1_g, k.ln1_b, M, W, W, 0, s));
-    CK(launch_gemm_f16(gemm(y, W, k.in_w, W, qkv, 3 * W, M, 3 * W, W, EPI_BIAS, k.in_b), h->gemm_variant, s));
+                  int nseq, int L, int W, int causal, hipStream_t s, float* stats = nullptr) {
+    const int M = nseq * L, H = W / 64, slots = W / 256;
+    if (stats) {
+        CK(launch_gemm_f16(gemm_ln(gemm(x, W, k.in_wf, W, qkv, 3 * W, M, 3 * W, W, EPI_LN_BIAS), stats, slots, k.in_g, k.in_bf), h->gemm_variant, s));
+    } else {
+        CK(launch_layernorm(x, y, k.ln1_g, k.ln1_b, M, W, W, 0, s));
+        CK(launch_gemm_f16(gemm(y, W, k.in_w, W, qkv, 3 * W, M, 3 * W, W, EPI_BIAS, k.in_b), h->gemm_variant, s));
+    }
     CK(launch_attention_f16(qkv, y, nseq, L, H, causal, h->attn_variant, s));
-    CK(launch_gemm_f16(gemm(y, W, k.out_w, W, x, W, M, W, W, EPI_BIAS_RES, k.out_b, x, W), h->gemm_variant, s));
-    CK(launch_layernorm(x, y, k.ln2_g, k.ln2_b, M, W, W, 0, s));
-    CK(launch_gemm_f16(gemm(y, W, k.fc_w, W, hid, 4 * W, M, 4 * W, W, EPI_BIAS_QGELU, k.fc_b), h->gemm_variant, s));
-    CK(launch_gemm_f16(gemm(hid, 4 * W, k.pj_w, 4 * W, x, W, M, W, 4 * W, EPI_BIAS_RES, k.pj_b, x, W), h->gemm_variant, s));
+    CK(launch_gemm_f16(gemm_stats(gemm(y, W, k.out_w, W, x, W, M, W, W, EPI_BIAS_RES, k.out_b, x, W), stats), h->gemm_variant, s));
+    if (stats) {
+        CK(launch_gemm_f16(gemm_ln(gemm(x, W, k.fc_wf, W, hid, 4 * W, M, 4 * W, W, EPI_LN_BIAS_QGELU), stats, slots, k.fc_g, k.fc_bf), h->gemm_variant, s));
+    } else {
+        CK(launch_layernorm(x, y, k.ln2_g, k.ln2_b, M, W, W, 0, s));
+        CK(launch_gemm_f16(gemm(y, W, k.fc_w, W, hid, 4 * W, M, 4 * W, W, EPI_BIAS_QGELU, k.fc_b), h->gemm_variant, s));
+    }
+    CK(launch_gemm_f16(gemm_stats(gemm(hid, 4 * W, k.pj_w, 4 * W, x, W, M, W, 4 * W, EPI_BIAS_RES, k.pj_b, x, W), stats), h->gemm_variant, s));
     return 0;
 }
 
@@ -198,9 +227,11 @@ int normalize_rows(ovmr_handle* h, half_t* x, int rows, int D, int mode, hipStre
 
 // Text tower after the embedding: blocks, gather, ln_final, projection (clip/model.py:824-831).
 int run_text_tower(ovmr_handle* h, half_t* x, half_t* y, half_t* qkv, half_t* hid, half_t* rows, const int* index,
-                   int N, int Ls, half_t* out, int normalize, hipStream_t s) {
+                   int N, int Ls, half_t* out, int normalize, hipStream_t s, float* stats_buf) {
     const int W = h->d.transformer_width;
-    for (auto& k : h->txt) CK(run_block_f16(h, k, x, y, qkv, hid, N, Ls, W, 1, s));
+    float* stats = !h->txt.empty() && can_fold_ln(h, h->txt[0], N * Ls, W) ? stats_buf : nullptr;
+    if (stats) CK(launch_row_stats(x, stats, N * Ls, W, W / 256, s));
+    for (auto& k : h->txt) CK(run_block_f16(h, k, x, y, qkv, hid, N, Ls, W, 1, s, stats));
     CK(launch_gather_rows_f16(x, index, rows, N, Ls, W, s));
     CK(launch_layernorm(rows, rows, h->ln_final_g, h->ln_final_b, N, W, W, 0, s));
     CK(launch_gemm_f16(gemm(rows, W, h->textproj_t, W, out, h->d.embed_dim, N, h->d.embed_dim, W, EPI_NONE), h->gemm_variant, s));
@@ -241,6 +272,7 @@ int ovmr_set_option(ovmr_handle* h, const char* key, int value) {
     if (!h || !key) return OVMR_E_ARG;
     if (!strcmp(key, "gemm")) h->gemm_variant = value;
     else if (!strcmp(key, "attn")) h->attn_variant = value;
+    else if (!strcmp(key, "ln_fold")) h->ln_fold = value;
     else return fail(h, OVMR_E_NAME, "unknown option '%s'", key);
     return 0;
 }
@@ -350,6 +382,20 @@ int ovmr_finalize(ovmr_handle* h, int max_images, int max_prompts, int max_class
     CK(launch_cast(tpos->p, 1, h->pos16_txt, 0, (long)d.context_length * T, s));
     CK(launch_transpose_to_f16(tproj->p, 0, h->textproj_t, (int)T, (int)E, s));
 
+    // LayerNorm folded into in_proj / c_fc of the two fp16 towers (common.h EPI_LN_BIAS)
+    for (auto* tower : {&h->vis, &h->txt}) {
+        const size_t Wd = tower == &h->vis ? W : T;
+        if (Wd % 256) continue;                                                  // the statistics come in 256-column slots
+        for (Block& k : *tower) {
+            k.in_wf = (half_t*)dalloc(3 * Wd * Wd * 2); k.in_g = (float*)dalloc(3 * Wd * 4); k.in_bf = (float*)dalloc(3 * Wd * 4);
+            k.fc_wf = (half_t*)dalloc(4 * Wd * Wd * 2); k.fc_g = (float*)dalloc(4 * Wd * 4); k.fc_bf = (float*)dalloc(4 * Wd * 4);
+            if (!k.in_wf || !k.in_g || !k.in_bf || !k.fc_wf || !k.fc_g || !k.fc_bf)
+                return fail(h, OVMR_E_NOMEM, "hipMalloc failed for LayerNorm-folded weights");
+            CK(launch_fold_ln((const half_t*)k.in_w, k.ln1_g, k.ln1_b, (const half_t*)k.in_b, k.in_wf, k.in_g, k.in_bf, (int)(3 * Wd), (int)Wd, s));
+            CK(launch_fold_ln((const half_t*)k.fc_w, k.ln2_g, k.ln2_b, (const half_t*)k.fc_b, k.fc_wf, k.fc_g, k.fc_bf, (int)(4 * Wd), (int)Wd, s));
+        }
+    }
+
     // workspace: one arena, re-carved by each entry point (calls on one handle are stream ordered)
     h->max_images = max_images; h->max_prompts = max_prompts; h->max_classes = max_classes;
     h->agg_rows_cap = (long)max_classes * (d.n_ctx + 32);
@@ -388,6 +434,7 @@ int ovmr_encode_image(ovmr_handle* h, const void* image, int image_dtype, int B,
         half_t* qkv = c.take<half_t>((size_t)M * 3 * W);
         half_t* hid = c.take<half_t>((size_t)M * 4 * W);
         half_t* rows = c.take<half_t>((size_t)Bc * W);
+        float* stats_buf = c.take<float>((size_t)M * ((W + 255) / 256) * 2);
         half_t* out = (half_t*)out_f16 + (size_t)b0 * E;
         // K1/K2: conv1 as GEMM over patches, positional add in the epilogue, CLS row, ln_pre
         CK(launch_im2col((const char*)image + (size_t)b0 * px, image_dtype == OVMR_F32, col, Bc, R, d.vision_patch_size, h->Kpad, s));
@@ -396,7 +443,9 @@ int ovmr_encode_image(ovmr_handle* h, const void* image, int image_dtype, int B,
         CK(launch_gemm_f16(pe, h->gemm_variant, s));
         CK(launch_fill_cls(x, h->cls_pos16, Bc, L, W, s));
         CK(launch_layernorm(x, x, h->ln_pre_g, h->ln_pre_b, M, W, W, 0, s));
-        for (size_t li = 0; li + 1 < h->vis.size(); ++li) CK(run_block_f16(h, h->vis[li], x, y, qkv, hid, Bc, L, W, 0, s));
+        float* stats = can_fold_ln(h, h->vis[0], M, W) ? stats_buf : nullptr;
+        if (stats) CK(launch_row_stats(x, stats, M, W, W / 256, s));
+        for (size_t li = 0; li + 1 < h->vis.size(); ++li) CK(run_block_f16(h, h->vis[li], x, y, qkv, hid, Bc, L, W, 0, s, stats));
         // Last block: only the CLS row reaches ln_post (clip/model.py:423), so after the K/V projection of all
         // tokens, attention / out-proj / MLP run for the CLS query row only -- identical result, ~6 % fewer FLOPs.
         {
@@ -404,8 +453,12 @@ int ovmr_encode_image(ovmr_handle* h, const void* image, int image_dtype, int B,
             const int H = W / 64;
             half_t* hid_c = hid;                       // [Bc, 4W]
             half_t* yc = y;                            // [Bc, W]
-            CK(launch_layernorm(x, y, k.ln1_g, k.ln1_b, M, W, W, 0, s));
-            CK(launch_gemm_f16(gemm(y, W, k.in_w, W, qkv, 3 * W, M, 3 * W, W, EPI_BIAS, k.in_b), h->gemm_variant, s));
+            if (stats) {
+                CK(launch_gemm_f16(gemm_ln(gemm(x, W, k.in_wf, W, qkv, 3 * W, M, 3 * W, W, EPI_LN_BIAS), stats, W / 256, k.in_g, k.in_bf), h->gemm_variant, s));
+            } else {
+                CK(launch_layernorm(x, y, k.ln1_g, k.ln1_b, M, W, W, 0, s));
+                CK(launch_gemm_f16(gemm(y, W, k.in_w, W, qkv, 3 * W, M, 3 * W, W, EPI_BIAS, k.in_b), h->gemm_variant, s));
+            }
             CK(launch_attention_f16_q(qkv, yc, Bc, L, 1, H, 0, h->attn_variant, s));
             CK(launch_gemm_f16(gemm(yc, W, k.out_w, W, rows, W, Bc, W, W, EPI_BIAS_RES, k.out_b, x, L * W), h->gemm_variant, s));
             CK(launch_layernorm(rows, yc, k.ln2_g, k.ln2_b, Bc, W, W, 0, s));
@@ -438,8 +491,9 @@ int ovmr_encode_text_embedded(ovmr_handle* h, const void* prompts_f16, const int
         half_t* qkv = c.take<half_t>(M * 3 * W);
         half_t* hid = c.take<half_t>(M * 4 * W);
         half_t* rows = c.take<half_t>((size_t)Nc * W);
+        float* stats_buf = c.take<float>(M * ((W + 255) / 256) * 2);
         CK(launch_text_add_pos((const half_t*)prompts_f16 + (size_t)n0 * Lc * W, Lc, h->pos16_txt, x, Nc, seq_len, W, s));
-        CK(run_text_tower(h, x, y, qkv, hid, rows, index + n0, Nc, seq_len, (half_t*)out_f16 + (size_t)n0 * E, normalize, s));
+        CK(run_text_tower(h, x, y, qkv, hid, rows, index + n0, Nc, seq_len, (half_t*)out_f16 + (size_t)n0 * E, normalize, s, stats_buf));
     }
     return 0;
 }
@@ -463,8 +517,9 @@ int ovmr_encode_text_ids(ovmr_handle* h, const int64_t* ids, int N, int seq_len,
         half_t* hid = c.take<half_t>(M * 4 * W);
         half_t* rows = c.take<half_t>((size_t)Nc * W);
         int* index = c.take<int>((size_t)Nc);
+        float* stats_buf = c.take<float>(M * ((W + 255) / 256) * 2);
         CK(launch_text_embed_ids(ids + (size_t)n0 * Lc, Lc, h->tok_emb, h->pos16_txt, x, index, Nc, Lc, seq_len, W, s));
-        CK(run_text_tower(h, x, y, qkv, hid, rows, index, Nc, seq_len, (half_t*)out_f16 + (size_t)n0 * E, normalize, s));
+        CK(run_text_tower(h, x, y, qkv, hid, rows, index, Nc, seq_len, (half_t*)out_f16 + (size_t)n0 * E, normalize, s, stats_buf));
     }
     return 0;
 }
@@ -624,7 +679,47 @@ int ovmr_debug_gemm(int f32, int variant, const void* A, const void* W, const vo
         a.w_blocked = (atoi(e) >> 1) & 1;
     }
     a.pos = pos; a.scale = scale; a.rows_in = rows_in; a.rows_out = rows_out;
+    if (epi == EPI_LN_BIAS || epi == EPI_LN_BIAS_QGELU) {   // LN-folding epilogues: bias = ln_b fp32 [N], pos = ln_g fp32 [N], res = statistics fp32 [M][K/256][2]
+        a.ln_b = (const float*)bias; a.ln_g = (const float*)pos; a.ln_stats = (const float*)res; a.ln_slots = K / 256;
+        a.bias = nullptr; a.pos = nullptr; a.res = nullptr;
+    }
+    if (epi == EPI_BIAS_RES && pos) {                       // statistics epilogue: pos = fp32 [M][N/256][2] output
+        a.stats_out = (float*)pos;
+        a.pos = nullptr;
+    }
     return f32 ? launch_gemm_f32(a, (hipStream_t)stream) : launch_gemm_f16(a, variant, (hipStream_t)stream);
+}
+
+// x1 = h(h(A1 W1^T + b1) + res) with the statistics epilogue, then C2 = h(LN(x1; gamma, beta) W2^T + b2) [QuickGELU] with
+// the LayerNorm folded into the second GEMM.  Scratch is allocated here (debug / kernel-test hook only).
+int ovmr_debug_lnfold(int variant, const void* A1, const void* W1, const void* b1, const void* res, int M, int D, int K1,
+                      const void* W2, const float* gamma, const float* beta, const void* b2, int N2, int qgelu,
+                      void* x1, void* C2, ovmr_stream stream) {
+    hipStream_t s = (hipStream_t)stream;
+    if (D % 256 || N2 % 64) return OVMR_E_ARG;
+    const int slots = D / 256;
+    float *stats = nullptr, *g = nullptr, *bf = nullptr;
+    half_t* wf = nullptr;
+    int rc = 0;
+    if (hipMalloc((void**)&stats, (size_t)M * slots * 8) != hipSuccess || hipMalloc((void**)&g, (size_t)N2 * 4) != hipSuccess ||
+        hipMalloc((void**)&bf, (size_t)N2 * 4) != hipSuccess || hipMalloc((void**)&wf, (size_t)N2 * D * 2) != hipSuccess)
+        rc = OVMR_E_NOMEM;
+    if (!rc) rc = launch_fold_ln((const half_t*)W2, gamma, beta, (const half_t*)b2, wf, g, bf, N2, D, s);
+    if (!rc && A1) {
+        GemmArgs a = gemm(A1, K1, W1, K1, x1, D, M, D, K1, EPI_BIAS_RES, b1, res, D);
+        a.stats_out = stats;
+        rc = launch_gemm_f16(a, variant, s);
+    } else if (!rc) {
+        rc = launch_row_stats((const half_t*)x1, stats, M, D, slots, s);     // A1 == NULL: x1 is an input
+    }
+    if (!rc) {
+        GemmArgs a = gemm(x1, D, wf, D, C2, N2, M, N2, D, qgelu ? EPI_LN_BIAS_QGELU : EPI_LN_BIAS);
+        a.ln_stats = stats; a.ln_slots = slots; a.ln_g = g; a.ln_b = bf;
+        rc = launch_gemm_f16(a, variant, s);
+    }
+    (void)hipStreamSynchronize(s);
+    (void)hipFree(stats); (void)hipFree(g); (void)hipFree(bf); (void)hipFree(wf);
+    return rc;
 }
 
 int ovmr_debug_layernorm(int f32, const void* x, void* y, const float* g, const float* b, int rows, int D,

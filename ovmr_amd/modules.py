@@ -346,18 +346,8 @@ class CustomCLIP:
             self.zero_shot_classifier = self.prompt_learner.zero_shot_classifier = text_clf
         assert bool(self.inference_text_initialized.bool().all()), "a class received no exemplar batch"   # :259
 
-        # K18-K20: cross-validation argmax counts on the exemplars this rank encoded, F1, softmax(tau*F1)
-        counts = torch.zeros((3, 2, C), dtype=torch.int32, device=dev)
-        if local.numel():
-            rows = self.eval_feat4cls[local].flatten(0, 1)
-            row_labels = local.to(torch.int32).repeat_interleave(S)                # :261
-            for m, clf in enumerate((self.mm_classifier, self.visual_classifer, self.zero_shot_classifier)):   # order :272
-                e.xval_counts(rows, row_labels, clf, counts[m, 0], counts[m, 1])
-        if dist:
-            dist.all_reduce(counts)
-        n_label = torch.full((C,), S, dtype=torch.int32, device=dev)
-        self.fusion_weight = e.fusion_weights(counts, n_label, float(self.cfg.EVAL_TAU))   # :273
-        self.xval_counts = counts
+        self.fusion_weight = self._xval_fusion_weight(local, self.mm_classifier, self.visual_classifer,
+                                                      self.zero_shot_classifier, float(self.cfg.EVAL_TAU))   # :261-274
         if rank == 0 and self.cfg.OUTPUT_DIR:
             os.makedirs(self.cfg.OUTPUT_DIR, exist_ok=True)
             torch.save({"text_classifier": self.zero_shot_classifier.float(),      # :276-285, all fp32
@@ -368,6 +358,48 @@ class CustomCLIP:
             torch.save({"visual_tokens": self.visual_tokens},                       # :286-291, fp16
                        osp.join(self.cfg.OUTPUT_DIR, "visual_tokens.pt"))
         return self.mm_classifier, self.visual_classifer, self.fusion_weight
+
+    def _xval_fusion_weight(self, local, mm_classifier, v_classifier, t_classifier, tau: float):
+        """K18-K20: cross-validation argmax counts on the exemplars this rank encoded (`local` = their class labels,
+        features in self.eval_feat4cls), all-reduced over ranks, then F1 and softmax(tau * F1).  Column order mm, v, t."""
+        e, dev, dist = self.engine, self.device, self._dist
+        C, S = len(self.tokenized_prompts), self.test_num_ins
+        counts = torch.zeros((3, 2, C), dtype=torch.int32, device=dev)
+        if local.numel():
+            rows = self.eval_feat4cls[local].flatten(0, 1)
+            row_labels = local.to(torch.int32).repeat_interleave(S)                # :261
+            for m, clf in enumerate((mm_classifier, v_classifier, t_classifier)):   # order :272
+                e.xval_counts(rows, row_labels, clf, counts[m, 0], counts[m, 1])
+        if dist:
+            dist.all_reduce(counts)
+        n_label = torch.full((C,), S, dtype=torch.int32, device=dev)
+        self.xval_counts = counts
+        return e.fusion_weights(counts, n_label, tau)
+
+    @torch.no_grad()
+    def get_fusion_weight(self, eval_set_loader: Iterable, mm_classifier, v_classifier, t_classifier):
+        """trainers/coop_mm_classifier.py:235-305: fusion weights for EXTERNALLY supplied classifiers [C, out].
+        Encodes the exemplar set, then the same cross-validation F1 preference as forward_prompt with tau fixed at 10
+        (:297).  The reference's [S, C, .] permuted feature layout (:277, :285-287) is undone before the row flatten,
+        so rows are r = c*S + s with label c exactly as in forward_prompt; nothing is written to disk."""
+        e, dev, dist = self.engine, self.device, self._dist
+        C, S, D = len(self.tokenized_prompts), self.test_num_ins, e.spec.embed_dim
+        rank, world = (dist.get_rank(), dist.get_world_size()) if dist else (0, 1)
+        self.eval_feat4cls = torch.zeros((C, S, D), dtype=torch.float16, device=dev)
+        presharded = bool(getattr(eval_set_loader, "presharded", False))
+        local_labels = []
+        for batch_idx, batch in enumerate(eval_set_loader):
+            if not presharded and batch_idx % world != rank:
+                continue
+            image = self._batch_images(batch, dev)
+            label = batch["label"].to(dev, non_blocking=True)
+            exemplar_label = label.reshape(image.shape[0] // S, S)[:, 0]              # :261
+            self.eval_feat4cls[exemplar_label] = e.encode_image(image, normalize=True).reshape(-1, S, D)   # :263-267
+            local_labels.append(exemplar_label)
+        local = torch.cat(local_labels) if local_labels else torch.zeros(0, dtype=torch.long, device=dev)
+        clfs = [c.to(device=dev, dtype=torch.float16).contiguous() for c in (mm_classifier, v_classifier, t_classifier)]
+        self.fusion_weight = self._xval_fusion_weight(local, *clfs, 10.0)
+        return self.fusion_weight
 
     @torch.no_grad()
     def forward(self, image, label=None, eval_set_loader=None, scale_no=None):

@@ -54,6 +54,7 @@ SIGNATURES = {
     "ovmr_flops_per_image": (ctypes.c_double, [c_p]),
     "ovmr_flops_per_prompt": (ctypes.c_double, [c_p, c_i]),
     "ovmr_debug_gemm": (c_i, [c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, ctypes.c_float, c_i, c_i, c_p]),
+    "ovmr_debug_lnfold": (c_i, [c_i, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_i, c_i, c_p, c_p, c_p]),
     "ovmr_debug_layernorm": (c_i, [c_i, c_p, c_p, c_p, c_p, c_i, c_i, ctypes.c_long, c_p]),
     "ovmr_debug_attention": (c_i, [c_i, c_i, c_p, c_p, c_i, c_i, c_i, c_i, c_p]),
 }

@@ -112,7 +112,16 @@ def _run(rank, world, port, outdir, result):
     loader = [{"img": img[s:s + S], "label": torch.from_numpy(labels[s:s + S])} for s in range(0, C * S, S)]  # 6 batches
     q = torch.from_numpy(synth.images(5, spec.image_resolution, 777))
     out = model(q, eval_set_loader=loader)
+    w_gen = model.fusion_weight.clone()
+    # coop_mm_classifier.get_fusion_weight variant: same exemplars, externally supplied classifiers, tau fixed at 10
+    w_coop = model.get_fusion_weight(loader, model.mm_classifier.float(), model.visual_classifer, model.zero_shot_classifier)
+    assert torch.equal(w_coop, w_gen)
     if rank == 0:
+        from oracle import ovmr_oracle as O
+        ref = O.get_fusion_weight_coop(model.eval_feat4cls if world == 1 else None, model.mm_classifier,
+                                       model.visual_classifer, model.zero_shot_classifier,
+                                       torch.tensor(model.engine.logit_scale)) if world == 1 else w_coop
+        assert torch.allclose(ref, w_coop, atol=1e-6)
         torch.save({"out": out, "mm": model.mm_classifier, "v": model.visual_classifer, "t": model.zero_shot_classifier,
                     "w": model.fusion_weight, "counts": model.xval_counts, "tokens": model.visual_tokens}, result)
     if world > 1:

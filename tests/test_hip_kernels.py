@@ -10,7 +10,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 EPI_NONE, EPI_BIAS, EPI_BIAS_QGELU, EPI_BIAS_RES, EPI_PATCH, EPI_SCALE = range(6)
-GEMM_VARIANTS = [0, 1, 2, 3, 4, 6, 8, 9, 10, 11]
+GEMM_VARIANTS = [0, 1, 2, 3, 4, 6, 11]
 ATTN_VARIANTS = [0, 1]
 
 
@@ -164,3 +164,61 @@ def test_attention_f32(lib, B, L, H):
     assert lib.ovmr_debug_attention(1, 0, _p(qd), _p(out), B, L, H, 0, _s()) == 0
     torch.cuda.synchronize()
     np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), atol=2e-5, rtol=1e-4)
+
+
+@pytest.mark.parametrize("variant", [6, 0])          # 0: the dispatcher must route LN-folding GEMMs to the v5 kernel itself
+@pytest.mark.parametrize("M,D,K1,N2,qgelu,produce", [
+    (197 * 3, 768, 768, 2304, 0, True), (1000, 768, 3072, 3072, 1, True), (256, 256, 64, 128, 0, True),
+    (513, 512, 2048, 1536, 0, True), (300, 1024, 1024, 4096, 1, True), (462, 512, 0, 2048, 1, False),
+])
+def test_gemm_layernorm_fold(lib, variant, M, D, K1, N2, qgelu, produce):
+    """EPI_BIAS_RES with the statistics epilogue, then LayerNorm folded into the next GEMM (common.h EPI_LN_BIAS):
+    compared with the reference order of operations -- fp32 LayerNorm rounded to fp16, then nn.Linear (clip/model.py:153-194) --
+    and with an unrounded fp64 statement: the folded path must be as close to exact as the reference's own path is."""
+    g = torch.Generator().manual_seed(M + D + N2)
+    res = torch.randn(M, D, generator=g)
+    res[:, 5] *= 20.0                                   # an outlier channel, as CLIP's residual stream has
+    res += torch.randn(D, generator=g) * 0.5            # per-channel offsets -> non-zero row means
+    res = res.half()
+    gamma, beta = 1.0 + 0.3 * torch.randn(D, generator=g), 0.2 * torch.randn(D, generator=g)
+    W2 = (torch.randn(N2, D, generator=g) * D ** -0.5).half()
+    b2 = (torch.randn(N2, generator=g) * 0.1).half()
+    d = "cuda"
+    if produce:
+        A1 = (torch.randn(M, K1, generator=g) * 0.5).half()
+        W1 = (torch.randn(D, K1, generator=g) * K1 ** -0.5).half()
+        b1 = (torch.randn(D, generator=g) * 0.1).half()
+        x1_ref = _ref_gemm_f16(A1, W1, b1, res, None, EPI_BIAS_RES, 1.0, 0, 0)
+        A1d, W1d, b1d = A1.to(d), W1.to(d), b1.to(d)
+    else:
+        x1_ref = res.float()
+    x1 = res.clone().to(d)
+    C2 = torch.zeros(M, N2, dtype=torch.float16, device=d)
+    gd, bd, W2d, b2d = gamma.to(d), beta.to(d), W2.to(d), b2.to(d)
+    rc = lib.ovmr_debug_lnfold(variant, _p(A1d) if produce else None, _p(W1d) if produce else None, _p(b1d) if produce else None,
+                               _p(x1), M, D, K1, _p(W2d), _p(gd), _p(bd), _p(b2d), N2, qgelu, _p(x1), _p(C2), _s())
+    assert rc == 0
+    torch.cuda.synchronize()
+    got_x1 = x1.float().cpu()
+    tol1 = 2e-3 * max(1.0, float(x1_ref.abs().max()))
+    assert float((got_x1 - x1_ref).abs().max()) <= tol1
+    # second GEMM: evaluate both statements on the x1 the device produced
+    ln64 = torch.nn.functional.layer_norm(got_x1.double(), (D,), gamma.double(), beta.double(), 1e-5)
+    ln16 = _h(torch.nn.functional.layer_norm(got_x1, (D,), gamma, beta, 1e-5))
+
+    def tail(u):
+        if not qgelu:
+            return u
+        return u * torch.sigmoid(1.702 * u)
+    exact = tail(ln64 @ W2.double().t() + b2.double())
+    u_ref = _h((ln16.double() @ W2.double().t() + b2.double()).float())
+    ref = _h(u_ref * _h(torch.sigmoid(_h(1.702 * u_ref)))) if qgelu else u_ref
+    got = C2.float().cpu()
+    assert torch.isfinite(got).all()
+    err_got = float((got.double() - exact).pow(2).mean().sqrt())
+    err_ref = float((ref.double() - exact).pow(2).mean().sqrt())
+    assert err_got <= 1.25 * err_ref + 1e-5, f"folded rms error {err_got:.3e} vs reference path {err_ref:.3e}"
+    tol = 4e-3 * max(1.0, float(ref.abs().max()))
+    assert float((got - ref).abs().max()) <= tol, f"max err {(got - ref).abs().max()}"
+    cos = torch.nn.functional.cosine_similarity(got, ref, dim=1)
+    assert float((1 - cos).max()) < 1e-5

@@ -57,6 +57,29 @@ def test_encode_image_vs_golden(golden, name, key, n_img):
         assert_cosine(f, g["l1_fp32_image_features"], COS_TOL, "image features vs reference fp32 path")
 
 
+def test_layernorm_fold_on_off_vs_golden(golden):
+    """ln_1 / ln_2 folded into the GEMM epilogues (default) and the separate LayerNorm kernels must both sit inside the
+    parity bar against the reference's recorded features, and next to each other."""
+    g = golden("vitb16")
+    e = _clip("ViT-B/16").engine(2)
+    img = torch.from_numpy(synth.images(8, 224, seed=1234))
+    out = {}
+    try:
+        for fold in (0, 1):
+            e.set_option("ln_fold", fold)
+            out[fold] = e.encode_image(img, normalize=False).float().cpu().numpy()
+            assert_cosine(out[fold], g["l1_fp16_image_features"], COS_TOL, f"ln_fold={fold} vs reference fp16 path")
+            assert_cosine(out[fold], g["l1_fp32_image_features"], COS_TOL, f"ln_fold={fold} vs reference fp32 path")
+    finally:
+        e.set_option("ln_fold", 1)
+    assert_cosine(out[0], out[1], 1e-5, "folded vs separate LayerNorm")
+    assert not np.array_equal(out[0], out[1]), "ln_fold=0 and ln_fold=1 ran the same kernels"
+    # distance to the fp32 reference: folding must not cost accuracy
+    ref = g["l1_fp32_image_features"]
+    d = [float(np.abs(out[f] - ref).mean()) for f in (0, 1)]
+    assert d[1] <= 1.3 * d[0] + 1e-6, f"mean abs error folded {d[1]:.3e} vs separate {d[0]:.3e}"
+
+
 @pytest.mark.parametrize("name,key", [("tiny", "tiny"), ("small", "small"), ("ViT-B/16", "vitb16")])
 def test_encode_text_ids_and_zeroshot_vs_golden(golden, name, key):
     g = golden(key)
@@ -66,7 +89,7 @@ def test_encode_text_ids_and_zeroshot_vs_golden(golden, name, key):
     t = e.encode_text_ids(ids, normalize=0)
     assert_cosine(t.float().cpu().numpy(), g["l1_fp16_text_features"], COS_TOL, "text features")
     t_short = e.encode_text_ids(ids, seq_len=int(ids.argmax(-1).max()) + 1, normalize=0)      # causal truncation is exact
-    assert_cosine(t_short.float().cpu().numpy(), t.float().cpu().numpy(), 1e-6, "truncated text")
+    assert_cosine(t_short.float().cpu().numpy(), t.float().cpu().numpy(), 1e-5, "truncated text")   # (>= 256 token rows fold ln_1/ln_2 into the GEMMs, fewer do not)
     # zsclip raw logits (trainers/zsclip.py:55-60)
     from ovmr_amd.modules import ZeroshotCLIP
     n_img = g["l1_fp16_image_features"].shape[0]
@@ -169,6 +192,39 @@ def test_generate_classifier_vs_golden(golden, tmp_path, O, name, key, tag, n_ct
         assert_cosine(outs[mode].cpu().numpy(), g[f"{tag}_logits_{mode}"], 5 * COS_TOL if name == "tiny" else COS_TOL, mode)
     if clear.all():
         assert_cosine(outs["fusion"].cpu().numpy(), g[f"{tag}_logits_fusion"], 5 * COS_TOL if name == "tiny" else COS_TOL, "fusion")
+
+
+def test_get_fusion_weight_coop_variant(golden, O):
+    """coop_mm_classifier.get_fusion_weight: externally supplied classifiers, tau fixed at 10."""
+    from ovmr_amd import modules
+    g = golden("small")
+    spec = synth.SPECS["small"]
+    S, cpb = int(g["meta_shots"]), int(g["meta_classes_per_batch"])
+    cfg = modules.make_cfg(n_ctx=2, num_shots=S, eval_tau=3.0, output_dir="")       # tau of the cfg must NOT be used
+    pl_sd = {k: torch.from_numpy(v) for k, v in synth.prompt_learner_state_dict(spec, 2, SEED, True).items()}
+    model = modules.CustomCLIP(cfg, torch.from_numpy(g["l2_tokenized_prompts"]), _clip("small"), prompt_learner_state=pl_sd,
+                               reserve=(64, 64, 256))
+    labels = g["l2_eval_labels"]
+    img = synth.images(len(labels), spec.image_resolution, seed=1234, class_ids=labels, class_strength=0.6)
+    step = cpb * S
+    loader = [{"img": torch.from_numpy(img[s:s + step]), "label": torch.from_numpy(labels[s:s + step])}
+              for s in range(0, len(labels), step)]
+    gen = torch.Generator().manual_seed(5)
+    centers = torch.from_numpy(g["l2_saved_vision_classifier"])
+    clfs = [torch.nn.functional.normalize(centers + s * torch.randn(centers.shape, generator=gen), dim=-1) for s in (0.0, 0.2, 0.6)]
+    w = model.get_fusion_weight(loader, *clfs)
+    assert w.shape == (6, 3) and w.dtype == torch.float32 and model.mm_classifier is None
+    assert_cosine(model.eval_feat4cls.float().cpu().numpy(), g["l2_eval_feat4cls"], COS_TOL, "eval_feat4cls")
+    ref = O.get_fusion_weight_coop(model.eval_feat4cls.cpu(), *[c.half() for c in clfs], torch.tensor(float(model.engine.logit_scale)))
+    counts = model.xval_counts.cpu()
+    from_counts = torch.stack([O.f1_from_counts(counts[m, 0], counts[m, 1], torch.full((6,), S)) for m in range(3)], -1)
+    np.testing.assert_allclose(w.cpu().numpy(), (10.0 * from_counts).softmax(-1).numpy(), atol=1e-6)
+    clear = np.ones(6 * S, dtype=bool)
+    for c in clfs:
+        lg = O.cross_validation_logits(model.eval_feat4cls.cpu(), c.half(), torch.tensor(float(model.engine.logit_scale)))
+        clear &= _margin_ok_rows(lg.float().numpy(), 0.26)
+    if clear.all():
+        np.testing.assert_allclose(w.cpu().numpy(), ref.numpy(), atol=1e-5)
 
 
 def test_fusion_head_vs_oracle(O):

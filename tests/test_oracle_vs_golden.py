@@ -172,3 +172,15 @@ def test_tokenizer_fixture(golden):
     assert ((eos >= 4) & (eos <= 7)).all() and (t[np.arange(50), eos] == synth.EOT_ID).all()
     assert (t[:, 0] == synth.SOT_ID).all() and (t[:, 1] == synth.TOK_A).all()
     assert (t[np.arange(50), eos - 1] == synth.TOK_DOT).all()
+
+
+@pytest.mark.parametrize("key,tag", [("tiny", "l2"), ("small", "l2"), ("vitb16", "l2")])
+def test_coop_fusion_weight_variant_equals_recorded(golden, key, tag):
+    """trainers/coop_mm_classifier.py:235-305 on the reference's own recorded features and classifiers: its permuted
+    [S, C, .] layout and fixed tau = 10 must reproduce the fusion weights the reference saved (recorded with tau = 10)."""
+    g = golden(key)
+    assert float(g["meta_tau"]) == 10.0
+    feats = torch.from_numpy(g[f"{tag}_eval_feat4cls"]).half()
+    clf = [torch.from_numpy(g[f"{tag}_saved_{k}"]).half() for k in ("mm_classifier", "vision_classifier", "text_classifier")]
+    w = O.get_fusion_weight_coop(feats, *clf, torch.tensor(float(np.exp(np.log(100.0)))))
+    np.testing.assert_allclose(w.numpy(), g[f"{tag}_saved_fusion_weight"], atol=1e-6)

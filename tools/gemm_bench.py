@@ -30,6 +30,7 @@ def main():
     dev = "cuda"
     M = args.batch * 197
     shapes = [("qkv", M, 2304, 768, 1), ("out_proj", M, 768, 768, 3), ("c_fc", M, 3072, 768, 2), ("c_proj", M, 768, 3072, 3),
+              ("qkv_ln", M, 2304, 768, 6), ("c_fc_ln", M, 3072, 768, 7), ("out_proj_st", M, 768, 768, 13), ("c_proj_st", M, 768, 3072, 13),
               ("patch", args.batch * 196, 768, 768, 0), ("text_qkv", 1000 * 10, 1536, 512, 1), ("xval_logits", 16000, 1000, 512, 5)]
     p = lambda t: ctypes.c_void_p(t.data_ptr())
     s = lambda: ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -43,16 +44,28 @@ def main():
         b = (torch.randn((n,), generator=g, device=dev) * 0.1).half()
         C = torch.zeros((m, n), dtype=torch.float16, device=dev)
         res = {}
+        # LayerNorm-folding epilogues (csrc/common.h): 6/7 consume row statistics, 13 = BIAS_RES that also emits them
+        st = torch.zeros((m, max(k, n) // 256 + 1, 2), device=dev)
+        st[:, 0, 1] = float(k)
+        lg, lb = torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+        if epi in (6, 7):
+            call = lambda v: lib.ovmr_debug_gemm(0, v, p(A), p(W), p(lb), p(st), p(lg), p(C), m, n, k, n, epi, 100.0, 0, 0, s())
+        elif epi == 13:
+            call = lambda v: lib.ovmr_debug_gemm(0, v, p(A), p(W), p(b), p(C), p(st), p(C), m, n, k, n, 3, 100.0, 0, 0, s())
+        else:
+            call = lambda v: lib.ovmr_debug_gemm(0, v, p(A), p(W), p(b), p(C) if epi == 3 else None, None, p(C), m, n, k, n, epi, 100.0, 0, 0, s())
+        if epi in (6, 7, 13) and any(12 <= v <= 19 or v in (21, 22) for v in args.variants):
+            continue                                  # timing-only ablation variants carry no LN-folding epilogues
         for v in args.variants:
             for _ in range(3):
-                assert lib.ovmr_debug_gemm(0, v, p(A), p(W), p(b), p(C) if epi == 3 else None, None, p(C), m, n, k, n, epi, 100.0, 0, 0, s()) == 0
+                assert call(v) == 0
         torch.cuda.synchronize()
         for r in range(args.rounds):
             for v in args.variants:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 for _ in range(args.reps):
-                    lib.ovmr_debug_gemm(0, v, p(A), p(W), p(b), p(C) if epi == 3 else None, None, p(C), m, n, k, n, epi, 100.0, 0, 0, s())
+                    call(v)
                 e1.record()
                 torch.cuda.synchronize()
                 res.setdefault(v, []).append(e0.elapsed_time(e1) * 1000 / args.reps)
