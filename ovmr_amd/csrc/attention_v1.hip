@@ -4,9 +4,13 @@
 //   * V kept row-major [key][d] like K (128-byte rows, chunk c of row r in slot c ^ (r & 7)) and consumed
 //     through ds_read_b64_tr_b16: per 16-lane group the instruction reads 4 keys x 16 d and hands lane i
 //     the 4 keys of column d0+i -- exactly the V^T fragment (A operand of O^T = V^T P^T);
-//   * two 16-row query tiles per wave (8 per workgroup): K/V of a (sequence, head) are staged 2x instead
-//     of 4x at L = 197.
+//   * two 16-row query tiles per wave and up to 8 waves per workgroup: at L = 197 ONE 7-wave workgroup covers a
+//     (sequence, head), so its K/V are read from HBM once (the kernel moves ~4 TB/s at the image shape: it is closer to
+//     the HBM roofline than to the MFMA one); both tiles of a wave share every K / V fragment read from LDS.
 #include "common.h"
+
+#include <algorithm>
+#include <cstdlib>
 
 namespace {
 
@@ -21,17 +25,21 @@ __device__ __forceinline__ half4_t tr_read(const half_t* p) {
 }
 
 template <bool CAUSAL>
-__global__ __launch_bounds__(256) void attn_f16_v1(const half_t* __restrict__ qkv, half_t* __restrict__ out,
-                                                   int L, int Lq, int H, int nT, int nWG, float scale_log2e) {
+__global__ __launch_bounds__(512, 4) void attn_f16_v1(const half_t* __restrict__ qkv, half_t* __restrict__ out,
+                                                   int L, int Lq, int H, int nT, int nWG, int nBH, float scale_log2e) {
     __shared__ __attribute__((aligned(16))) half_t smem[2 * 2 * KB1 * 64];   // [buf][K|V][64 keys][64 d]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fr = lane & 15, fg = lane >> 4;
     const int D = H * 64, ld = 3 * D;
-    const int wg = blockIdx.x % nWG, bh = blockIdx.x / nWG;
+    // the workgroups of one (sequence, head) get block ids congruent mod 8: same XCD, so the second one finds K / V in that L2
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int wg = slot % nWG, bh = (slot / nWG) * 8 + xcd;
+    if (bh >= nBH) return;
     const int h = bh % H, b = bh / H;
-    const int t0 = (wg * nT) / nWG, t1 = ((wg + 1) * nT) / nWG;        // up to 8 query tiles
+    const int t0 = (wg * nT) / nWG, t1 = ((wg + 1) * nT) / nWG;        // up to 16 query tiles
+    const int nW = (int)blockDim.x >> 6;                               // waves: ceil(tiles per workgroup / 2)
     const half_t* base = qkv + (long)b * L * ld + h * 64;
 
     int qrow[2];
@@ -39,7 +47,7 @@ __global__ __launch_bounds__(256) void attn_f16_v1(const half_t* __restrict__ qk
     half8_t qf[2][2];
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-        const int qt = t0 + wave + 4 * u;
+        const int qt = t0 + wave + nW * u;
         act[u] = qt < t1;
         qrow[u] = qt * 16 + fr;
         const int qc = min(qrow[u], L - 1);
@@ -53,13 +61,11 @@ __global__ __launch_bounds__(256) void attn_f16_v1(const half_t* __restrict__ qk
 #pragma unroll
         for (int i = 0; i < 4; ++i) o[u][i] = (float4_t){0.f, 0.f, 0.f, 0.f};
 
-    // staging: 16 LDS-DMA instructions per block (8 K + 8 V), 4 per wave; one instruction = 8 rows x 128 B
+    // staging: 16 LDS-DMA instructions per block (8 K + 8 V) dealt round-robin to the waves; one instruction = 8 rows x 128 B
     const int srow = lane >> 3, schunk = ((lane & 7) ^ srow) * 8;
     auto stage = [&](int buf, int k0) {
         half_t* dst = smem + buf * (2 * KB1 * 64);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int ins = wave * 4 + j;                 // 0..7: K rows, 8..15: V rows
+        for (int ins = wave; ins < 16; ins += nW) {       // 0..7: K rows, 8..15: V rows
             const int isv = ins >> 3, r0 = (ins & 7) * 8;
             const int kc = min(k0 + r0 + srow, L - 1);
             __builtin_amdgcn_global_load_lds((gptr_t)(base + (1 + isv) * D + (long)kc * ld + schunk),
@@ -67,7 +73,7 @@ __global__ __launch_bounds__(256) void attn_f16_v1(const half_t* __restrict__ qk
         }
     };
 
-    const int last_tile = min(t1 - 1, t0 + 7);
+    const int last_tile = t1 - 1;
     const int kmax = CAUSAL ? min(L, (last_tile + 1) * 16) : L;
     const int nb = (kmax + KB1 - 1) / KB1;
     stage(0, 0);
@@ -80,23 +86,38 @@ __global__ __launch_bounds__(256) void attn_f16_v1(const half_t* __restrict__ qk
         const half_t* sK = smem + (kb & 1) * (2 * KB1 * 64);
         const half_t* sV = sK + KB1 * 64;
         const int k0 = kb * KB1;
+        // Both query tiles of the wave go through a key block TOGETHER: every K fragment and every transposed V fragment
+        // is read from LDS once and feeds two MFMAs (one per tile).  With one tile at a time the LDS pipe was ~90 % busy
+        // (16 KiB of fragment reads per (tile, block) against 16 MFMAs) and set the pace, not the matrix cores.
+        bool on[2];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            if (!act[u] || (CAUSAL && k0 > (t0 + wave + 4 * u) * 16 + 15)) continue;     // wave-uniform
-            const int q = qrow[u];
-            float4_t s[4];
+        for (int u = 0; u < 2; ++u) on[u] = act[u] && !(CAUSAL && k0 > (t0 + wave + nW * u) * 16 + 15);   // wave-uniform
+        if (!on[0] && !on[1]) continue;
+        // 16-key sub-tiles / 32-key halves of this block that hold any valid key (L = 197: the last block has 5 keys)
+        const int nvalid = min(kmax - k0, KB1);
+        const int ntv = (nvalid + 15) >> 4, nsv = (nvalid + 31) >> 5;
+        float4_t s[2][4];
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt) {
-                s[nt] = (float4_t){0.f, 0.f, 0.f, 0.f};
+        for (int nt = 0; nt < 4; ++nt) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) s[u][nt] = (float4_t){0.f, 0.f, 0.f, 0.f};
+            if (nt < ntv) {
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
-                    half8_t kf = *(const half8_t*)(sK + (nt * 16 + fr) * 64 + ((((ks << 2) + fg) ^ (fr & 7)) << 3));
-                    s[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[u][ks], s[nt], 0, 0, 0);
+                    const half8_t kf = *(const half8_t*)(sK + (nt * 16 + fr) * 64 + ((((ks << 2) + fg) ^ (fr & 7)) << 3));
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) s[u][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[u][ks], s[u][nt], 0, 0, 0);
                 }
             }
+        }
+        half8_t pf[2][2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int q = qrow[u];
             // raw-score maximum first (masking only in blocks that need it: the last key block, or the diagonal blocks of
-            // the causal case), then p = exp2(fma(s, scale*log2e, -max*scale*log2e)): one VALU op less per element
-            const bool need_mask = (k0 + KB1 > L) || (CAUSAL && k0 + KB1 - 1 > (t0 + wave + 4 * u) * 16);   // wave-uniform
+            // the causal case), then p = exp2(fma(s, scale*log2e, -max*scale*log2e)): one VALU op less per element.
+            // A tile that is switched off for this block sees every key masked: alpha = 1, p = 0, nothing changes.
+            const bool need_mask = !on[u] || (k0 + KB1 > L) || (CAUSAL && k0 + KB1 - 1 > (t0 + wave + nW * u) * 16);   // wave-uniform
             float mx = -INFINITY;
             if (need_mask) {
 #pragma unroll
@@ -104,14 +125,14 @@ __global__ __launch_bounds__(256) void attn_f16_v1(const half_t* __restrict__ qk
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int key = k0 + nt * 16 + fg * 4 + r;
-                        const bool ok = (key < L) && (!CAUSAL || key <= q);
-                        s[nt][r] = ok ? s[nt][r] : -INFINITY;
+                        const bool ok = on[u] && (key < L) && (!CAUSAL || key <= q);
+                        s[u][nt][r] = ok ? s[u][nt][r] : -INFINITY;
                     }
             }
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[nt][r]);
+                for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[u][nt][r]);
             mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
             const float m_new = fmaxf(m_run[u], mx * scale_log2e);        // running maximum kept in the scaled domain
@@ -121,8 +142,8 @@ __global__ __launch_bounds__(256) void attn_f16_v1(const half_t* __restrict__ qk
             for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[nt][r], scale_log2e, -m_new));
-                    s[nt][r] = p;
+                    const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[u][nt][r], scale_log2e, -m_new));
+                    s[u][nt][r] = p;
                     psum += p;
                 }
             psum += __shfl_xor(psum, 16, 64);
@@ -132,24 +153,27 @@ __global__ __launch_bounds__(256) void attn_f16_v1(const half_t* __restrict__ qk
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) o[u][dt] *= alpha;
 #pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) {
-                half8_t pf;
+            for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    pf[j] = (half_t)s[2 * s2][j];
-                    pf[4 + j] = (half_t)s[2 * s2 + 1][j];
+                    pf[u][s2][j] = (half_t)s[u][2 * s2][j];
+                    pf[u][s2][4 + j] = (half_t)s[u][2 * s2 + 1][j];
                 }
-                // V^T fragment through the transposing read: lane (fr, fg) addresses key row kr, 4 d-columns
-                const int kr = s2 * 32 + fg * 4 + (fr >> 2);
+        }
 #pragma unroll
-                for (int dt = 0; dt < 4; ++dt) {
-                    const int c = dt * 2 + ((fr & 3) >> 1);
-                    const int off = (((c ^ (kr & 7)) << 3) + (fr & 1) * 4);      // halves; (kr+16)&7 == kr&7
-                    half4_t v0 = tr_read(sV + kr * 64 + off);
-                    half4_t v1 = tr_read(sV + (kr + 16) * 64 + off);
-                    half8_t vf = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-                    o[u][dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf, o[u][dt], 0, 0, 0);
-                }
+        for (int s2 = 0; s2 < 2; ++s2) {
+            if (s2 >= nsv) continue;
+            // V^T fragment through the transposing read: lane (fr, fg) addresses key row kr, 4 d-columns
+            const int kr = s2 * 32 + fg * 4 + (fr >> 2);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const int c = dt * 2 + ((fr & 3) >> 1);
+                const int off = (((c ^ (kr & 7)) << 3) + (fr & 1) * 4);      // halves; (kr+16)&7 == kr&7
+                half4_t v0 = tr_read(sV + kr * 64 + off);
+                half4_t v1 = tr_read(sV + (kr + 16) * 64 + off);
+                half8_t vf = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+#pragma unroll
+                for (int u = 0; u < 2; ++u) o[u][dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf[u][s2], o[u][dt], 0, 0, 0);
             }
         }
     }
@@ -171,10 +195,15 @@ __global__ __launch_bounds__(256) void attn_f16_v1(const half_t* __restrict__ qk
 }  // namespace
 
 int launch_attention_f16_v1(const half_t* qkv, half_t* out, int B, int L, int Lq, int H, int causal, hipStream_t s) {
-    const int nT = (Lq + 15) / 16, nWG = (nT + 7) / 8;
+    static int tpw = 0;                                    // query tiles per workgroup (debug: OVMR_ATTN_TPW)
+    if (!tpw) { const char* e = getenv("OVMR_ATTN_TPW"); tpw = e ? atoi(e) : 8; if (tpw < 2 || tpw > 16) tpw = 8; }   // 8 (4 waves x 2 tiles) measured best: 16 -> 198 us, 8 -> 193 us, 4 -> 321 us at B = 512
+    const int nT = (Lq + 15) / 16, nWG = (nT + tpw - 1) / tpw;
+    const int per = (nT + nWG - 1) / nWG;                  // most tiles any workgroup gets
+    const dim3 block(64 * std::max(4, (per + 1) / 2));      // at least 4 waves: the spare ones only help staging K / V
     const float sl2e = 0.125f * 1.4426950408889634f;
-    const dim3 grid((unsigned)((long)B * H * nWG));
-    if (causal) hipLaunchKernelGGL(attn_f16_v1<true>, grid, dim3(256), 0, s, qkv, out, L, Lq, H, nT, nWG, sl2e);
-    else hipLaunchKernelGGL(attn_f16_v1<false>, grid, dim3(256), 0, s, qkv, out, L, Lq, H, nT, nWG, sl2e);
+    const int nBH = B * H;
+    const dim3 grid((unsigned)((long)((nBH + 7) / 8) * 8 * nWG));
+    if (causal) hipLaunchKernelGGL(attn_f16_v1<true>, grid, block, 0, s, qkv, out, L, Lq, H, nT, nWG, nBH, sl2e);
+    else hipLaunchKernelGGL(attn_f16_v1<false>, grid, block, 0, s, qkv, out, L, Lq, H, nT, nWG, nBH, sl2e);
     return (int)hipGetLastError();
 }

@@ -212,7 +212,8 @@ __global__ __launch_bounds__(512) void gemm_f16_v5_kernel(GemmArgs a, int tiles_
     for (int h = 0; h < MT / 4; ++h) {
         __syncthreads();                                // main-loop reads / previous half's reads are done
         // residual rows of this half: requested now, consumed after phase 1 (their latency used to sit in front of every
-        // store: ~6 us per 256x256 tile on out_proj / c_proj)
+        // store: ~6 us per 256x256 tile on out_proj / c_proj).  Requesting them earlier -- the first half under the last
+        // K-tile's MFMAs (249 VGPRs), or both halves here -- measured 4-7 % SLOWER on out_proj / c_proj.
         half8_t res8[EPI == EPI_BIAS_RES ? 8 : 1];
         if (EPI == EPI_BIAS_RES) {
             const int nn = n0 + wn * 64 + ec;

@@ -8,7 +8,7 @@ from ovmr_amd import runtime
 lib = runtime.load_library()
 p = lambda t: ctypes.c_void_p(t.data_ptr())
 s = lambda: ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-for name, B, L, H, causal in (("image", 256, 197, 12, 0), ("text", 1000, 10, 8, 1), ("vit-l336", 32, 577, 16, 0)):
+for name, B, L, H, causal in (("image", 512, 197, 12, 0), ("text", 1000, 10, 8, 1), ("text77", 256, 77, 8, 1), ("vit-l336", 32, 577, 16, 0)):
     qkv = torch.randn((B * L, 3 * H * 64), device="cuda").half()
     out = torch.empty((B * L, H * 64), device="cuda", dtype=torch.float16)
     res = {}
