@@ -154,7 +154,7 @@ def main():
     roof = measure_roofline(eng, spec, args, dev) if rank == 0 else None
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(spec, sd, pl, tok, args, n_ctx)
+        cpu = cpu_baseline(spec, sd, pl, tok, args, n_ctx) if args.cpu_sample_classes > 0 else None   # 0: profiling runs skip the CPU leg
 
     if rank == 0:
         flops_img = eng.flops_per_image()
