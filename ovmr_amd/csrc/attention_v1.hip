@@ -4,9 +4,13 @@
 //   * V kept row-major [key][d] like K (128-byte rows, chunk c of row r in slot c ^ (r & 7)) and consumed
 //     through ds_read_b64_tr_b16: per 16-lane group the instruction reads 4 keys x 16 d and hands lane i
 //     the 4 keys of column d0+i -- exactly the V^T fragment (A operand of O^T = V^T P^T);
-//   * two 16-row query tiles per wave and up to 8 waves per workgroup: at L = 197 ONE 7-wave workgroup covers a
-//     (sequence, head), so its K/V are read from HBM once (the kernel moves ~4 TB/s at the image shape: it is closer to
-//     the HBM roofline than to the MFMA one); both tiles of a wave share every K / V fragment read from LDS.
+//   * (r01g) the VALU issue port bounds this kernel (75 % busy against ~20 % for the MFMA pipe, tools/pmc_attn.sh): lazy
+//     rescaling against a reference maximum and row sums from the matrix pipe cut vector instructions (194 -> 183 us);
+//     a variant with a specialised body for complete unmasked key blocks spilled registers at the 128-VGPR cap and ran
+//     at 255 us -- not kept;
+//   * two 16-row query tiles per wave, 4 waves (8 tiles) per workgroup, both tiles of a wave sharing every K / V fragment
+//     read from LDS; <= 128 VGPRs, i.e. 4 waves per SIMD (3 waves/SIMD: 233 us instead of 193 at B = 512); the workgroups
+//     of a head run on one XCD; 16 tiles / 7 waves per workgroup (K/V read once) measured 198 us, 4 tiles 321 us.
 #include "common.h"
 
 #include <algorithm>
@@ -54,7 +58,17 @@ __global__ __launch_bounds__(512, 4) void attn_f16_v1(const half_t* __restrict__
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) qf[u][ks] = *(const half8_t*)(base + (long)qc * ld + ks * 32 + fg * 8);
     }
-    float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.f, 0.f};
+    // m_run: the reference maximum the exponentials are taken against (scaled domain).  It only moves when a block's
+    // maximum exceeds it by more than 8 (a factor 256 in p, harmless for fp16 P and fp32 accumulators): then o and the row
+    // sums are rescaled.  After the first key block that is rare, so the 16 packed multiplies and the exp of the usual
+    // every-block rescale disappear.  The row sums are accumulated by the matrix pipe (ones . P^T, accumulator ol), not by
+    // 32 VALU adds and two cross-lane shuffles per tile: the VALU issue port is what bounds this kernel (75 % busy,
+    // profiles/r01g_pmc_attn.json), the MFMA pipe is not.
+    float m_run[2] = {-INFINITY, -INFINITY};
+    float4_t ol[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    half8_t ones;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ones[j] = (half_t)1.f;
     float4_t o[2][4];
 #pragma unroll
     for (int u = 0; u < 2; ++u)
@@ -99,15 +113,18 @@ __global__ __launch_bounds__(512, 4) void attn_f16_v1(const half_t* __restrict__
         float4_t s[2][4];
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
-#pragma unroll
-            for (int u = 0; u < 2; ++u) s[u][nt] = (float4_t){0.f, 0.f, 0.f, 0.f};
             if (nt < ntv) {
+                const float4_t zero = {0.f, 0.f, 0.f, 0.f};
+                const half8_t kf0 = *(const half8_t*)(sK + (nt * 16 + fr) * 64 + ((fg ^ (fr & 7)) << 3));
+                const half8_t kf1 = *(const half8_t*)(sK + (nt * 16 + fr) * 64 + (((4 + fg) ^ (fr & 7)) << 3));
 #pragma unroll
-                for (int ks = 0; ks < 2; ++ks) {
-                    const half8_t kf = *(const half8_t*)(sK + (nt * 16 + fr) * 64 + ((((ks << 2) + fg) ^ (fr & 7)) << 3));
-#pragma unroll
-                    for (int u = 0; u < 2; ++u) s[u][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[u][ks], s[u][nt], 0, 0, 0);
+                for (int u = 0; u < 2; ++u) {
+                    s[u][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf0, qf[u][0], zero, 0, 0, 0);
+                    s[u][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf1, qf[u][1], s[u][nt], 0, 0, 0);
                 }
+            } else {
+#pragma unroll
+                for (int u = 0; u < 2; ++u) s[u][nt] = (float4_t){0.f, 0.f, 0.f, 0.f};
             }
         }
         half8_t pf[2][2];
@@ -135,23 +152,21 @@ __global__ __launch_bounds__(512, 4) void attn_f16_v1(const half_t* __restrict__
                 for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[u][nt][r]);
             mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            const float m_new = fmaxf(m_run[u], mx * scale_log2e);        // running maximum kept in the scaled domain
-            const float alpha = __builtin_amdgcn_exp2f(m_run[u] - m_new);   // raw v_exp_f32: arguments are <= 0
-            float psum = 0.f;
+            const float mxs = mx * scale_log2e;
+            if (__builtin_amdgcn_ballot_w64(mxs > m_run[u] + 8.0f) != 0) {     // wave-uniform: some row needs a new reference
+                const float m_new = fmaxf(m_run[u], mxs);
+                const float alpha = __builtin_amdgcn_exp2f(m_run[u] - m_new);   // raw v_exp_f32: arguments are <= 0 (first block: -inf)
+                m_run[u] = m_new;
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) o[u][dt] *= alpha;
+                ol[u] *= alpha;
+            }
+            const float m_ref = m_run[u];
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[u][nt][r], scale_log2e, -m_new));
-                    s[u][nt][r] = p;
-                    psum += p;
-                }
-            psum += __shfl_xor(psum, 16, 64);
-            psum += __shfl_xor(psum, 32, 64);
-            l_run[u] = l_run[u] * alpha + psum;
-            m_run[u] = m_new;
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) o[u][dt] *= alpha;
+                for (int r = 0; r < 4; ++r)
+                    s[u][nt][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[u][nt][r], scale_log2e, -m_ref));
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
@@ -175,12 +190,14 @@ __global__ __launch_bounds__(512, 4) void attn_f16_v1(const half_t* __restrict__
 #pragma unroll
                 for (int u = 0; u < 2; ++u) o[u][dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf[u][s2], o[u][dt], 0, 0, 0);
             }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) ol[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ones, pf[u][s2], ol[u], 0, 0, 0);   // row sums
         }
     }
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
         if (act[u] && qrow[u] < Lq) {
-            const float inv = 1.0f / l_run[u];
+            const float inv = 1.0f / ol[u][0];            // every d-row of ones . P^T holds the row sum of this lane's query
             half_t* op = out + ((long)b * Lq + qrow[u]) * D + h * 64 + fg * 4;
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {

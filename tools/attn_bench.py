@@ -5,10 +5,17 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from ovmr_amd import runtime
 
+import argparse
+ap = argparse.ArgumentParser()
+ap.add_argument("--only", default="")
+ap.add_argument("--reps", type=int, default=10)
+args = ap.parse_args()
 lib = runtime.load_library()
 p = lambda t: ctypes.c_void_p(t.data_ptr())
 s = lambda: ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 for name, B, L, H, causal in (("image", 512, 197, 12, 0), ("text", 1000, 10, 8, 1), ("text77", 256, 77, 8, 1), ("vit-l336", 32, 577, 16, 0)):
+    if args.only and name != args.only:
+        continue
     qkv = torch.randn((B * L, 3 * H * 64), device="cuda").half()
     out = torch.empty((B * L, H * 64), device="cuda", dtype=torch.float16)
     res = {}
@@ -18,9 +25,9 @@ for name, B, L, H, causal in (("image", 512, 197, 12, 0), ("text", 1000, 10, 8, 
                 assert lib.ovmr_debug_attention(0, v, p(qkv), p(out), B, L, H, causal, s()) == 0
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            for _ in range(10):
+            for _ in range(args.reps):
                 lib.ovmr_debug_attention(0, v, p(qkv), p(out), B, L, H, causal, s())
             e1.record(); torch.cuda.synchronize()
-            res.setdefault(v, []).append(e0.elapsed_time(e1) * 100)
+            res.setdefault(v, []).append(e0.elapsed_time(e1) * 1000 / args.reps)
     fl = 4.0 * B * H * L * L * 64
     print(name, {f"v{v}": {"us": round(min(t), 1), "tflops": round(fl / min(t) / 1e6, 1)} for v, t in res.items()}, flush=True)

@@ -1,0 +1,29 @@
+#!/bin/bash
+# PMC passes over tools/attn_bench.py (image shape only): counters in their own runs, --kernel-trace only.
+# usage: tools/pmc_attn.sh <outdir>
+OUT=${1:-gpurun_out/pmc_attn}; R=${GRAFT_REPO_ROOT:-$(pwd)}
+mkdir -p $R/$OUT; cd /tmp; export TMPDIR=/tmp
+run() { name=$1; shift; timeout 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $R/$OUT/$name -- python3 $R/tools/attn_bench.py --only image --reps 2 > $R/$OUT/$name.log 2>&1; }
+run sq1 SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES GRBM_GUI_ACTIVE
+run sq2 SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_VALU SQ_ACTIVE_INST_VALU
+run sq3 SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_MISC SQ_ACTIVE_INST_SCA SQ_INSTS_LDS SQ_INSTS_SALU
+run mem FETCH_SIZE WRITE_SIZE TCC_HIT_sum TCC_MISS_sum
+cd $R
+python3 - <<PY
+import csv, glob, collections, json
+out = collections.defaultdict(dict)
+for name in ("sq1", "sq2", "sq3", "mem"):
+    for f in glob.glob("$OUT/%s/**/*counter_collection.csv" % name, recursive=True):
+        agg = collections.defaultdict(lambda: collections.defaultdict(list))
+        for r in csv.DictReader(open(f)):
+            k = r["Kernel_Name"]
+            if "attn_f16_v1" not in k:
+                continue
+            agg["attn_f16_v1"][r["Counter_Name"]].append(float(r["Counter_Value"]))
+            agg["attn_f16_v1"]["duration_us_under_pmc"].append((float(r["End_Timestamp"]) - float(r["Start_Timestamp"])) / 1e3)
+        for key, c in agg.items():
+            for n, v in c.items():
+                out[key][n] = round(sum(v) / len(v), 2)
+json.dump(out, open("$OUT/summary.json", "w"), indent=1)
+print(json.dumps(out, indent=1))
+PY
