@@ -247,17 +247,20 @@ __global__ __launch_bounds__(512) void gemm_f16_v5_kernel(GemmArgs a, int tiles_
                 if (LNF) {
                     const float4_t c1 = *(const float4_t*)(col_c + BN5 + cc);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        float x = (float)(half_t)fmaf(ln_r, v[r], fmaf(ln_t, c0[r], c1[r]));
-                        if (EPI == EPI_LN_BIAS_QGELU) x = quick_gelu_h(x);
-                        o[r] = (half_t)x;
+                    for (int r = 0; r < 4; r += 2) {
+                        half2_t u2 = {(half_t)fmaf(ln_r, v[r], fmaf(ln_t, c0[r], c1[r])),
+                                      (half_t)fmaf(ln_r, v[r + 1], fmaf(ln_t, c0[r + 1], c1[r + 1]))};
+                        if (EPI == EPI_LN_BIAS_QGELU) u2 = quick_gelu_h2(u2);
+                        o[r] = u2[0];
+                        o[r + 1] = u2[1];
                     }
                 } else if (HAS_BIAS) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        float x = (float)(half_t)(v[r] + c0[r]);
-                        if (EPI == EPI_BIAS_QGELU) x = quick_gelu_h(x);
-                        o[r] = (half_t)x;
+                    for (int r = 0; r < 4; r += 2) {
+                        half2_t u2 = {(half_t)(v[r] + c0[r]), (half_t)(v[r + 1] + c0[r + 1])};
+                        if (EPI == EPI_BIAS_QGELU) u2 = quick_gelu_h2(u2);
+                        o[r] = u2[0];
+                        o[r + 1] = u2[1];
                     }
                 } else {
 #pragma unroll
