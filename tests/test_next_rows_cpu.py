@@ -128,3 +128,17 @@ def test_runner_helpers(tmp_path):
     a = cli.parse(["--root", "r", "--clip-weights", "w.pt", "--eval-only", "--load-epoch", "30", "--eval_tau", "5",
                    "DATASET.NUM_SHOTS", "8"])
     assert a.load_epoch == 30 and a.eval_tau == 5.0 and a.opts == ["DATASET.NUM_SHOTS", "8"]
+
+
+def test_loader_list_form_k_transforms():
+    """K_TRANSFORMS > 1 hands the model a LIST of image tensors (trainers/mm_classifier_one_prompt.py:229-234):
+    unsqueeze(1), cat on dim 1, flatten(0, 1) -> the k views of an image are consecutive rows."""
+    from ovmr_amd.modules import CustomCLIP
+    a = torch.arange(3 * 2, dtype=torch.float32).reshape(3, 2)          # 3 images, view 0
+    b = a + 100                                                          # view 1
+    out = CustomCLIP._batch_images({"img": [a, b]}, "cpu")
+    assert out.shape == (6, 2)
+    assert torch.equal(out, torch.stack([a, b], dim=1).flatten(0, 1))
+    assert torch.equal(out[0], a[0]) and torch.equal(out[1], b[0]) and torch.equal(out[2], a[1])
+    single = CustomCLIP._batch_images({"img": a}, "cpu")
+    assert single is a
