@@ -212,6 +212,7 @@ __global__ __launch_bounds__(512) void gemm_f16_v5_kernel(GemmArgs a, int tiles_
     char* et = smem + wave * (64 * EP);                 // this wave's 64-row x 64-column staging tile
     const int er = lane >> 3, ec = (lane & 7) * 8;     // phase 2: row within an 8-row group, first column
     const bool emit_stats = EPI == EPI_BIAS_RES && a.stats_out != nullptr;
+    const bool full_tile = EPI != EPI_PATCH && m0 + BM <= a.M && n0 + BN5 <= a.N;   // workgroup-uniform
     float* stat_lds = (float*)(smem + 8 * 64 * EP);      // [BM rows][4 column waves][2], behind the staging tiles
 #pragma unroll
     for (int h = 0; h < MT / 4; ++h) {
@@ -275,45 +276,65 @@ __global__ __launch_bounds__(512) void gemm_f16_v5_kernel(GemmArgs a, int tiles_
         }
         __syncthreads();
         const int nn = n0 + wn * 64 + ec;
+        // residual add + row statistics of one 8-column slice (EPI_BIAS_RES); 8 lanes share a row
+        auto finish = [&](half8_t v, int it, int row) -> half8_t {
+            if (EPI == EPI_BIAS_RES) {
+                const half8_t r8 = res8[EPI == EPI_BIAS_RES ? it : 0];
 #pragma unroll
-        for (int it = 0; it < 8; ++it) {
-            const int row = it * 8 + er;
-            const int m = m0 + wm * (BM / 2) + h * 64 + row;
-            if (m < a.M && nn < a.N) {                  // N % 8 == 0 is guaranteed by the launcher
-                half8_t v = *(const half8_t*)(et + row * EP + ec * 2);
-                long crow = m;
-                if (EPI == EPI_BIAS_RES) {
-                    const half8_t r8 = res8[EPI == EPI_BIAS_RES ? it : 0];
+                for (int k = 0; k < 8; ++k) v[k] = (half_t)((float)v[k] + (float)r8[k]);
+                if (emit_stats) {                       // statistics of the STORED fp16 row slice
+                    // v_dot2_f32_f16 (two fp16 products + fp32 accumulate) and DPP lane exchanges inside the 8-lane
+                    // group: 14 instructions where cvt/add chains and ds_bpermute shuffles took ~45 per store
+                    float su = 0.f, sq = 0.f;
+                    const half2_t one2 = {(half_t)1.f, (half_t)1.f};
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) v[k] = (half_t)((float)v[k] + (float)r8[k]);
-                    if (emit_stats) {                   // statistics of the STORED fp16 row slice (8 lanes share a row)
-                        // v_dot2_f32_f16 (two fp16 products + fp32 accumulate) and DPP lane exchanges inside the 8-lane
-                        // group: 14 instructions where cvt/add chains and ds_bpermute shuffles took ~45 per store
-                        float su = 0.f, sq = 0.f;
-                        const half2_t one2 = {(half_t)1.f, (half_t)1.f};
-#pragma unroll
-                        for (int k = 0; k < 8; k += 2) {
-                            const half2_t v2 = {v[k], v[k + 1]};
-                            su = __builtin_amdgcn_fdot2(v2, one2, su, false);
-                            sq = __builtin_amdgcn_fdot2(v2, v2, sq, false);
-                        }
-                        su += dpp_f32<0xB1>(su); sq += dpp_f32<0xB1>(sq);       // quad_perm [1,0,3,2]: lane ^ 1
-                        su += dpp_f32<0x4E>(su); sq += dpp_f32<0x4E>(sq);       // quad_perm [2,3,0,1]: lane ^ 2
-                        su += dpp_f32<0x141>(su); sq += dpp_f32<0x141>(sq);     // row_half_mirror: the other quad of the 8
-                        if ((lane & 7) == 0)
-                            *(float2_t*)(stat_lds + ((wm * (BM / 2) + h * 64 + row) * 4 + wn) * 2) = (float2_t){su, sq};
+                    for (int k = 0; k < 8; k += 2) {
+                        const half2_t v2 = {v[k], v[k + 1]};
+                        su = __builtin_amdgcn_fdot2(v2, one2, su, false);
+                        sq = __builtin_amdgcn_fdot2(v2, v2, sq, false);
                     }
+                    su += dpp_f32<0xB1>(su); sq += dpp_f32<0xB1>(sq);       // quad_perm [1,0,3,2]: lane ^ 1
+                    su += dpp_f32<0x4E>(su); sq += dpp_f32<0x4E>(sq);       // quad_perm [2,3,0,1]: lane ^ 2
+                    su += dpp_f32<0x141>(su); sq += dpp_f32<0x141>(sq);     // row_half_mirror: the other quad of the 8
+                    if ((lane & 7) == 0)
+                        *(float2_t*)(stat_lds + ((wm * (BM / 2) + h * 64 + row) * 4 + wn) * 2) = (float2_t){su, sq};
                 }
-                if (EPI == EPI_PATCH) {
-                    const int b = m / a.rows_in, p = m - b * a.rows_in;
-                    crow = (long)b * a.rows_out + 1 + p;
-                    half8_t p8 = *(const half8_t*)((const half_t*)a.pos + (long)(1 + p) * a.N + nn);
+            }
+            return v;
+        };
+        if (full_tile) {
+            // interior tile (all but the last row / column of tiles): the eight LDS reads go out back to back and the stores
+            // walk one pointer; the guarded loop below costs 13 instructions and one exposed LDS round trip per store
+            half8_t vv[8];
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) v[k] = (half_t)((float)v[k] + (float)p8[k]);
+            for (int it = 0; it < 8; ++it) vv[it] = *(const half8_t*)(et + (it * 8 + er) * EP + ec * 2);
+            half_t* dst = C + (long)(m0 + wm * (BM / 2) + h * 64 + er) * a.ldc + nn;
+            const long step = 8L * a.ldc;
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const half8_t v = finish(vv[it], it, it * 8 + er);
+                if (NT) __builtin_nontemporal_store(v, (half8_t*)(dst + it * step));
+                else if (!NOSTORE || (float)v[0] == 12345.678f) *(half8_t*)(dst + it * step) = v;
+            }
+        } else {
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int row = it * 8 + er;
+                const int m = m0 + wm * (BM / 2) + h * 64 + row;
+                if (m < a.M && nn < a.N) {                  // N % 8 == 0 is guaranteed by the launcher
+                    half8_t v = finish(*(const half8_t*)(et + row * EP + ec * 2), it, row);
+                    long crow = m;
+                    if (EPI == EPI_PATCH) {
+                        const int b = m / a.rows_in, p = m - b * a.rows_in;
+                        crow = (long)b * a.rows_out + 1 + p;
+                        half8_t p8 = *(const half8_t*)((const half_t*)a.pos + (long)(1 + p) * a.N + nn);
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) v[k] = (half_t)((float)v[k] + (float)p8[k]);
+                    }
+                    half8_t* dst = (half8_t*)(C + crow * a.ldc + nn);
+                    if (NT) __builtin_nontemporal_store(v, dst);
+                    else if (!NOSTORE || (float)v[0] == 12345.678f) *dst = v;   // NOSTORE: timing-only ablation
                 }
-                half8_t* dst = (half8_t*)(C + crow * a.ldc + nn);
-                if (NT) __builtin_nontemporal_store(v, dst);
-                else if (!NOSTORE || (float)v[0] == 12345.678f) *dst = v;   // NOSTORE: timing-only ablation
             }
         }
     }
