@@ -249,26 +249,29 @@ __global__ __launch_bounds__(512) void gemm_f16_v5_kernel(GemmArgs a, int tiles_
                     const float4_t c1 = *(const float4_t*)(col_c + BN5 + cc);
 #pragma unroll
                     for (int r = 0; r < 4; r += 2) {
-                        half2_t u2 = {(half_t)fmaf(ln_r, v[r], fmaf(ln_t, c0[r], c1[r])),
-                                      (half_t)fmaf(ln_r, v[r + 1], fmaf(ln_t, c0[r + 1], c1[r + 1]))};
+                        const float2_t x2 = {fmaf(ln_r, v[r], fmaf(ln_t, c0[r], c1[r])), fmaf(ln_r, v[r + 1], fmaf(ln_t, c0[r + 1], c1[r + 1]))};
+                        half2_t u2 = __builtin_convertvector(x2, half2_t);
                         if (EPI == EPI_LN_BIAS_QGELU) u2 = quick_gelu_h2(u2);
                         o[r] = u2[0];
                         o[r + 1] = u2[1];
                     }
-                } else if (HAS_BIAS) {
+                } else {
+                    // float2 sums and __builtin_convertvector: v_pk_add_f32 + v_cvt_pk_f16_f32 (round to nearest even), two
+                    // elements per instruction; element-wise casts made hipcc emit cvt + pack + alignbit chains (3.8 -> ~1.6
+                    // vector instructions per element in this phase)
 #pragma unroll
                     for (int r = 0; r < 4; r += 2) {
-                        half2_t u2 = {(half_t)(v[r] + c0[r]), (half_t)(v[r + 1] + c0[r + 1])};
+                        float2_t x2 = {v[r], v[r + 1]};
+                        if (HAS_BIAS) x2 += (float2_t){c0[r], c0[r + 1]};
+                        half2_t u2 = __builtin_convertvector(x2, half2_t);
                         if (EPI == EPI_BIAS_QGELU) u2 = quick_gelu_h2(u2);
+                        if (EPI == EPI_SCALE) {                                   // h(h(acc) * scale)
+                            float2_t y2 = __builtin_convertvector(u2, float2_t);
+                            y2 *= a.scale;
+                            u2 = __builtin_convertvector(y2, half2_t);
+                        }
                         o[r] = u2[0];
                         o[r + 1] = u2[1];
-                    }
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        float x = (float)(half_t)v[r];
-                        if (EPI == EPI_SCALE) x *= a.scale;
-                        o[r] = (half_t)x;
                     }
                 }
                 *(half4_t*)(et + (i * 16 + fr) * EP + (j * 16 + fg * 4) * 2) = o;
