@@ -229,24 +229,30 @@ __global__ __launch_bounds__(512) void gemm_f16_v5_kernel(GemmArgs a, int tiles_
                 res8[EPI == EPI_BIAS_RES ? it : 0] = *(const half8_t*)((const half_t*)a.res + (long)m * a.ldres + min(nn, a.N - 8));
             }
         }
+        float ln_rs[LNF ? 4 : 1], ln_ts[LNF ? 4 : 1];   // LNF: rstd and -rstd * mean of this lane's four rows
+        if (LNF) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            float ln_r = 0.f, ln_t = 0.f;               // LNF: rstd and -rstd * mean of this lane's row
-            if (LNF) {
+            for (int i = 0; i < 4; ++i) {
                 const int r = wm * (BM / 2) + h * 64 + i * 16 + fr;
-                ln_r = row_c[r];
-                ln_t = row_c[BM + r];
+                ln_rs[LNF ? i : 0] = row_c[r];
+                ln_ts[LNF ? i : 0] = row_c[BM + r];
             }
+        }
+        // column tile outermost: its constants are read from LDS once per half tile (not once per 16x16 accumulator block).
+        // (Reading all of them into registers ahead of the h loop measured 4 % SLOWER on the LN-folding kernels: that
+        // changed the K loop's register allocation.)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < 4; ++j) {
+            const int cc = wn * 64 + j * 16 + fg * 4;
+            const float4_t c0 = *(const float4_t*)(col_c + cc);
+            float4_t c1 = c0;
+            if (LNF) c1 = *(const float4_t*)(col_c + BN5 + cc);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
                 const float4_t v = acc[h * 4 + i][j];
-                // (reading the column constants into registers once, ahead of the loop, measured 4 % SLOWER on the LN-folding
-                // kernels: the epilogue is not what it changes, the K loop's register allocation is)
-                const int cc = wn * 64 + j * 16 + fg * 4;
-                const float4_t c0 = *(const float4_t*)(col_c + cc);
+                const float ln_r = ln_rs[LNF ? i : 0], ln_t = ln_ts[LNF ? i : 0];
                 half4_t o;
                 if (LNF) {
-                    const float4_t c1 = *(const float4_t*)(col_c + BN5 + cc);
 #pragma unroll
                     for (int r = 0; r < 4; r += 2) {
                         const float2_t x2 = {fmaf(ln_r, v[r], fmaf(ln_t, c0[r], c1[r])), fmaf(ln_r, v[r + 1], fmaf(ln_t, c0[r + 1], c1[r + 1]))};
