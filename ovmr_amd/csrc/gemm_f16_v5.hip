@@ -216,7 +216,12 @@ __global__ __launch_bounds__(512) void gemm_f16_v5_kernel(GemmArgs a, int tiles_
     float* stat_lds = (float*)(smem + 8 * 64 * EP);      // [BM rows][4 column waves][2], behind the staging tiles
 #pragma unroll
     for (int h = 0; h < MT / 4; ++h) {
-        __syncthreads();                                // main-loop reads / previous half's reads are done
+        // The ONLY workgroup barrier of the epilogue: every wave's K-loop fragment reads must be done before staging tiles
+        // overwrite the K buffers.  The staging tile itself is private to its wave (LDS executes a wave's instructions in
+        // order), so neither the write -> read turn inside a half nor the read -> write turn between the halves needs one;
+        // the barriers that used to sit there also drained vmcnt, i.e. made every wave wait for the first half's global
+        // stores before converting the second half.
+        if (h == 0) __syncthreads();
         // residual rows of this half: requested now, consumed after phase 1 (their latency used to sit in front of every
         // store: ~6 us per 256x256 tile on out_proj / c_proj).  Requesting them earlier -- the first half under the last
         // K-tile's MFMAs (249 VGPRs), or both halves here -- measured 4-7 % SLOWER on out_proj / c_proj.
@@ -283,7 +288,6 @@ __global__ __launch_bounds__(512) void gemm_f16_v5_kernel(GemmArgs a, int tiles_
                 *(half4_t*)(et + (i * 16 + fr) * EP + (j * 16 + fg * 4) * 2) = o;
             }
         }
-        __syncthreads();
         const int nn = n0 + wn * 64 + ec;
         // residual add + row statistics of one 8-column slice (EPI_BIAS_RES); 8 lanes share a row
         auto finish = [&](half8_t v, int it, int row) -> half8_t {
