@@ -352,7 +352,10 @@ __global__ __launch_bounds__(512) void gemm_f16_v5_kernel(GemmArgs a, int tiles_
         }
     }
     if (emit_stats) {       // one (sum, sum of squares) pair per row and N tile, the four column waves added in fixed order
-        __syncthreads();
+        // LDS-only barrier: __syncthreads() would also wait for vmcnt(0), i.e. for this tile's global stores to drain
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
         if (tid < BM && m0 + tid < a.M) {
             const float* p = stat_lds + tid * 8;
             const float su = ((p[0] + p[2]) + p[4]) + p[6], sq = ((p[1] + p[3]) + p[5]) + p[7];
