@@ -154,16 +154,19 @@ __global__ __launch_bounds__(512) void gemm_f16_v5_kernel(GemmArgs a, int tiles_
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                  // tile kt landed for every wave; buffer (kt+1)&1 is free
         __builtin_amdgcn_sched_barrier(0);
-        if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
-
         const char* cur = smem + (kt & 1) * STAGE;
         half8_t fb[2][4], fa[3];
         // software-pipelined fragment reads: A fragment of step t+2 and the B fragments of the next k-step are
-        // issued before the MFMAs of step t; sched_group_barrier pins that order for the machine scheduler
+        // issued before the MFMAs of step t; sched_group_barrier pins that order for the machine scheduler.
+        // The first six reads go out BEFORE the next K-tile's eight LDS-DMA instructions: their LDS latency then runs
+        // under the DMA issue (address adds + VMEM issue) instead of after it (same-process A/B: within noise, kept).
 #pragma unroll
         for (int t = 0; t < 4; ++t) fb[0][t] = *(const half8_t*)(cur + b_row_off + t * 2048 + ch0);
         fa[0] = *(const half8_t*)(cur + a_row_off + ch0);
         fa[1] = *(const half8_t*)(cur + a_row_off + 2048 + ch0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int st = 0; st < MT; ++st) {
             const int nx = st + 2;
