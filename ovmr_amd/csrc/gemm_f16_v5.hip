@@ -32,7 +32,8 @@ __device__ __forceinline__ float dpp_f32(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
 }
 
-// OPT bits: 64 NOSTORE / 128 NOEPI (timing-only ablations, variants 18 / 19), 512 NT (nontemporal C stores)
+// OPT bits: 1 / 2 nontemporal LDS-DMA for the A / W operand, 64 NOSTORE / 128 NOEPI (timing-only ablations, variants
+// 18 / 19), 512 NT (nontemporal C stores)
 template <int EPI, int MT, int OPT>
 __global__ __launch_bounds__(512) void gemm_f16_v5_kernel(GemmArgs a, int tiles_m, int tiles_n) {
     constexpr int BM = MT * 32;
@@ -108,10 +109,10 @@ __global__ __launch_bounds__(512) void gemm_f16_v5_kernel(GemmArgs a, int tiles_
         char* base = smem + buf * STAGE;
 #pragma unroll
         for (int j = 0; j < AJ; ++j)
-            __builtin_amdgcn_global_load_lds((gptr_t)((const char*)A + oa[j] + (long)kt * a_step), (lptr_t)(base + ldsA_w + j * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)((const char*)A + oa[j] + (long)kt * a_step), (lptr_t)(base + ldsA_w + j * 1024), 16, 0, (OPT & 1) ? 2 : 0);
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-            __builtin_amdgcn_global_load_lds((gptr_t)((const char*)W + ob[j] + (long)kt * w_step), (lptr_t)(base + ldsB_w + j * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)((const char*)W + ob[j] + (long)kt * w_step), (lptr_t)(base + ldsB_w + j * 1024), 16, 0, (OPT & 2) ? 2 : 0);
     };
 
     float4_t acc[MT][4];
@@ -403,6 +404,13 @@ int launch_v5(const GemmArgs& a, hipStream_t s) {
         b.nt_store = force ? force : (b.epi != EPI_BIAS_RES && (size_t)b.M * b.N * 2 >= ((size_t)48 << 20) ? 2 : 1);
     }
     if (OPT == 0 && b.nt_store == 2) return launch_v5_k<EPI, MT, 512>(b, tiles_m, tiles_n, s);
+    // Residual projections (N <= 1024: at most four N tiles share an A panel): the A stream is loaded with the nontemporal
+    // policy so that it does not push the W panels every tile re-reads out of the L2 (out_proj 146 -> 141 us, c_proj 477 ->
+    // 459 us).  With 9-12 N tiles per A panel the same hint costs 6-11 %, and on the W operand it always costs.
+    static int a_nt_force = -1;
+    if (a_nt_force < 0) { const char* e = getenv("OVMR_A_NT"); a_nt_force = e ? atoi(e) : 0; }   // 1 = never, 2 = always (BIAS_RES only)
+    if (OPT == 0 && EPI == EPI_BIAS_RES && a_nt_force != 1 && (a_nt_force == 2 || (tiles_n <= 4 && tiles_m * tiles_n >= 512)))
+        return launch_v5_k<EPI, MT, (EPI == EPI_BIAS_RES ? 1 : 0)>(b, tiles_m, tiles_n, s);
     return launch_v5_k<EPI, MT, OPT>(b, tiles_m, tiles_n, s);
 }
 
