@@ -311,6 +311,33 @@ def test_missing_weight_fails_loudly():
         e.encode_image(torch.zeros(1, 3, 32, 32))
 
 
+def test_refinalize_and_weight_update():
+    """ovmr_finalize may be called again (larger reservation, or after a weight was replaced): the derived layouts --
+    padded conv weight, transposed projections, the LayerNorm-folded in_proj / c_fc copies -- are rebuilt, not stale."""
+    from ovmr_amd import modules
+    spec = synth.SPECS["small"]
+    sd = {k: torch.from_numpy(v) for k, v in synth.clip_state_dict(spec, SEED, jitter=True).items()}
+    cm = modules.CLIPModel(sd, spec)
+    e = cm.engine(2)
+    e.load_state_dict({}, {k: torch.from_numpy(v) for k, v in synth.prompt_learner_state_dict(spec, 2, SEED, True).items()})
+    e.finalize(24, 8, 8)
+    img = torch.from_numpy(synth.images(20, spec.image_resolution, seed=5))
+    a = e.encode_image(img, normalize=False).float().cpu()
+    e.finalize(32, 16, 64)                                     # bigger workspace, same weights (20 images = one chunk both times)
+    b = e.encode_image(img, normalize=False).float().cpu()
+    assert torch.equal(a, b)
+    # replace ln_1 gamma of block 0: the folded in_proj copy must follow (>= 256 token rows -> the folded path runs)
+    name = "visual.transformer.resblocks.0.ln_1.weight"
+    e.set_weight(name, sd[name] * 1.5)
+    e.finalize(32, 16, 64)
+    c = e.encode_image(img, normalize=False).float().cpu()
+    assert not torch.allclose(b, c, atol=1e-3)
+    e.set_option("ln_fold", 0)
+    d = e.encode_image(img, normalize=False).float().cpu()
+    e.set_option("ln_fold", 1)
+    assert_cosine(c.numpy(), d.numpy(), 1e-5, "folded vs separate LayerNorm after the weight update")
+
+
 def test_full_size_properties():
     """ViT-B/16 at the benchmark batch (256): size-independent properties -- batch invariance (an image's
     feature does not depend on its batch mates or position), unit norm, determinism."""
