@@ -426,7 +426,10 @@ int pick_v5(const GemmArgs& a, hipStream_t s) {
         const double t = (double)((a.M + bm - 1) / bm) * ((a.N + BN5 - 1) / BN5);
         return t / (ceil(t / 256.0) * 256.0);
     };
-    const bool big = g_force_mt ? g_force_mt == 8 : eff(256) + 0.08 >= eff(128);
+    // grids far below one round of CUs (the CLS-only tail of the last vision block: 512 rows): the smaller tile doubles the
+    // workgroups and shortens each K-tile (out_proj 22.5 -> 14.0 us, c_proj 67.7 -> 42.6 us at 512 rows)
+    const double t256 = (double)((a.M + 255) / 256) * ((a.N + BN5 - 1) / BN5);
+    const bool big = g_force_mt ? g_force_mt == 8 : (t256 >= 64 && eff(256) + 0.08 >= eff(128));
     return big ? launch_v5<EPI, 8, OPT>(a, s) : launch_v5<EPI, 4, OPT>(a, s);
 }
 

@@ -31,6 +31,7 @@ def main():
     M = args.batch * 197
     shapes = [("qkv", M, 2304, 768, 1), ("out_proj", M, 768, 768, 3), ("c_fc", M, 3072, 768, 2), ("c_fc_bias_only", M, 3072, 768, 1), ("n1536_bias", M, 1536, 768, 1), ("c_proj", M, 768, 3072, 3),
               ("qkv_ln", M, 2304, 768, 6), ("c_fc_ln", M, 3072, 768, 7), ("out_proj_st", M, 768, 768, 13), ("c_proj_st", M, 768, 3072, 13),
+              ("cls_out_proj", args.batch, 768, 768, 3), ("cls_c_fc", args.batch, 3072, 768, 2), ("cls_c_proj", args.batch, 768, 3072, 3),   # last block: CLS rows only
               ("patch", args.batch * 196, 768, 768, 0), ("text_qkv", 1000 * 10, 1536, 512, 1), ("xval_logits", 16000, 1000, 512, 5)]
     p = lambda t: ctypes.c_void_p(t.data_ptr())
     s = lambda: ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
