@@ -32,7 +32,8 @@ __device__ __forceinline__ float dpp_f32(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
 }
 
-// OPT bits: 1 / 2 nontemporal LDS-DMA for the A / W operand, 64 NOSTORE / 128 NOEPI (timing-only ablations, variants
+// OPT bits: 1 / 2 nontemporal LDS-DMA for the A / W operand, 4 K loop with the iteration boundary inside the MFMA stream (8: six
+// instead of two deferred steps), 64 NOSTORE / 128 NOEPI (timing-only ablations, variants
 // 18 / 19), 512 NT (nontemporal C stores)
 template <int EPI, int MT, int OPT>
 __global__ __launch_bounds__(512) void gemm_f16_v5_kernel(GemmArgs a, int tiles_m, int tiles_n) {
@@ -150,6 +151,67 @@ __global__ __launch_bounds__(512) void gemm_f16_v5_kernel(GemmArgs a, int tiles_
         row_c[BM + r] = -rstd * mean;
     }
 
+    if (OPT & 4) {
+    // K loop with the iteration boundary moved INSIDE the MFMA stream.  All of a K-tile's fragment reads are issued two steps
+    // before its last MFMAs, so the wait for the next tile's LDS-DMA, the workgroup barrier, the next tile's first six fragment
+    // reads and the LDS-DMA issue for the tile after it all happen in front of the last two steps (8 MFMAs per wave): the matrix
+    // pipe works through those while the new fragments are in flight, instead of every wave of the CU waiting on LDS at once.
+    constexpr int D = ((OPT & 8) && MT == 8) ? 6 : 2, R = D + 2;   // deferred steps (<= MT: they must all use fb[1]) / A-fragment ring
+    static_assert((2 * MT) % R == 0 && D <= MT, "");
+    half8_t fb[2][4], fa[R];
+    auto first_reads = [&](const char* buf) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) fb[0][t] = *(const half8_t*)(buf + b_row_off + t * 2048 + ch0);
+#pragma unroll
+        for (int t = 0; t < D; ++t) fa[t] = *(const half8_t*)(buf + a_row_off + (t % MT) * 2048 + (t / MT ? ch1 : ch0));
+    };
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    first_reads(smem);
+    __builtin_amdgcn_sched_barrier(0);
+    if (nk > 1) stage(1, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    for (int kt = 0; kt < nk; ++kt) {
+        const char* cur = smem + (kt & 1) * STAGE;
+#pragma unroll
+        for (int st = 0; st < 2 * MT - D; ++st) {
+            const int nx = st + D;
+            fa[nx % R] = *(const half8_t*)(cur + a_row_off + (nx % MT) * 2048 + (nx / MT ? ch1 : ch0));
+            if (st == 1) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) fb[1][t] = *(const half8_t*)(cur + b_row_off + t * 2048 + ch1);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[st % MT][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[st / MT][j], fa[st % R], acc[st % MT][j], 0, 0, 0);
+        }
+#pragma unroll
+        for (int st = 0; st < 2 * MT - D; ++st) {
+            if (st == 1) __builtin_amdgcn_sched_group_barrier(0x100, 5, 0);
+            else __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (kt + 1 < nk) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // tile kt+1 landed (issued one iteration ago)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // every fragment of tile kt is in registers
+            __builtin_amdgcn_s_barrier();                          // ... for every wave: buffer kt & 1 is free
+            __builtin_amdgcn_sched_barrier(0);
+            first_reads(smem + ((kt + 1) & 1) * STAGE);
+            __builtin_amdgcn_sched_barrier(0);
+            if (kt + 2 < nk) stage(kt & 1, kt + 2);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int st = 2 * MT - D; st < 2 * MT; ++st)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[st % MT][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[st / MT][j], fa[st % R], acc[st % MT][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    } else {
     for (int kt = 0; kt < nk; ++kt) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -202,6 +264,7 @@ __global__ __launch_bounds__(512) void gemm_f16_v5_kernel(GemmArgs a, int tiles_
         }
     }
 
+    }
     // ---------------------------------------------------------------- epilogue through LDS
     half_t* C = (half_t*)a.C;
     if (NOEPI) {            // timing-only ablation: the K loop alone (the store below never happens on real data)
@@ -404,13 +467,22 @@ int launch_v5(const GemmArgs& a, hipStream_t s) {
         b.nt_store = force ? force : (b.epi != EPI_BIAS_RES && (size_t)b.M * b.N * 2 >= ((size_t)48 << 20) ? 2 : 1);
     }
     if (OPT == 0 && b.nt_store == 2) return launch_v5_k<EPI, MT, 512>(b, tiles_m, tiles_n, s);
-    // Residual projections (N <= 1024: at most four N tiles share an A panel): the A stream is loaded with the nontemporal
-    // policy so that it does not push the W panels every tile re-reads out of the L2 (out_proj 146 -> 141 us, c_proj 477 ->
-    // 459 us).  With 9-12 N tiles per A panel the same hint costs 6-11 %, and on the W operand it always costs.
-    static int a_nt_force = -1;
-    if (a_nt_force < 0) { const char* e = getenv("OVMR_A_NT"); a_nt_force = e ? atoi(e) : 0; }   // 1 = never, 2 = always (BIAS_RES only)
-    if (OPT == 0 && EPI == EPI_BIAS_RES && a_nt_force != 1 && (a_nt_force == 2 || (tiles_n <= 4 && tiles_m * tiles_n >= 512)))
-        return launch_v5_k<EPI, MT, (EPI == EPI_BIAS_RES ? 1 : 0)>(b, tiles_m, tiles_n, s);
+    if constexpr (OPT == 0 && EPI == EPI_BIAS_RES) {
+        // Residual projections.
+        // (1) N <= 1024 (at most four N tiles share an A panel): the A stream is loaded with the nontemporal policy so that it
+        //     does not push the W panels every tile re-reads out of the L2 (out_proj 146 -> 141 us, c_proj 477 -> 459 us).  With
+        //     9-12 N tiles per A panel the same hint costs 6-11 %, and on the W operand it always costs.
+        // (2) K >= 2048: the K loop with the iteration boundary inside the MFMA stream (OPT & 4): c_proj 467 -> 449 us; at
+        //     K = 768 (12 K-tiles) it is neutral to 2 % slower.
+        static int a_nt_force = -1, ov_force = -1;
+        if (a_nt_force < 0) { const char* e = getenv("OVMR_A_NT"); a_nt_force = e ? atoi(e) : 0; }       // 1 = never, 2 = always
+        if (ov_force < 0) { const char* e = getenv("OVMR_K_OVERLAP"); ov_force = e ? atoi(e) : 0; }      // 1 = never, 2 = always
+        const bool a_nt = a_nt_force != 1 && (a_nt_force == 2 || (tiles_n <= 4 && tiles_m * tiles_n >= 512));
+        const bool ov = ov_force != 1 && (ov_force == 2 || b.K >= 2048);
+        if (a_nt && ov) return launch_v5_k<EPI, MT, 5>(b, tiles_m, tiles_n, s);
+        if (ov) return launch_v5_k<EPI, MT, 4>(b, tiles_m, tiles_n, s);
+        if (a_nt) return launch_v5_k<EPI, MT, 1>(b, tiles_m, tiles_n, s);
+    }
     return launch_v5_k<EPI, MT, OPT>(b, tiles_m, tiles_n, s);
 }
 
