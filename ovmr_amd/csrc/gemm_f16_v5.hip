@@ -466,6 +466,16 @@ int launch_v5(const GemmArgs& a, hipStream_t s) {
         if (force < 0) { const char* e = getenv("OVMR_NT_STORE"); force = e ? atoi(e) : 0; }
         b.nt_store = force ? force : (b.epi != EPI_BIAS_RES && (size_t)b.M * b.N * 2 >= ((size_t)48 << 20) ? 2 : 1);
     }
+    if constexpr (OPT == 0 && (EPI == EPI_LN_BIAS || EPI == EPI_LN_BIAS_QGELU)) {
+        // the LayerNorm-folding launches also run the K loop with the boundary inside the MFMA stream (qkv_ln 354 -> 343 us,
+        // c_fc_ln 525 -> 518 us; the plain bias / QuickGELU launches of the same shapes do not gain)
+        static int ov_force = -1;
+        if (ov_force < 0) { const char* e = getenv("OVMR_K_OVERLAP"); ov_force = e ? atoi(e) : 0; }
+        if (ov_force != 1) {
+            if (b.nt_store == 2) return launch_v5_k<EPI, MT, 4 | 512>(b, tiles_m, tiles_n, s);
+            return launch_v5_k<EPI, MT, 4>(b, tiles_m, tiles_n, s);
+        }
+    }
     if (OPT == 0 && b.nt_store == 2) return launch_v5_k<EPI, MT, 512>(b, tiles_m, tiles_n, s);
     if constexpr (OPT == 0 && EPI == EPI_BIAS_RES) {
         // Residual projections.
