@@ -42,7 +42,11 @@ __global__ __launch_bounds__(512, 4) void attn_f16_v1(const half_t* __restrict__
     const int wg = slot % nWG, bh = (slot / nWG) * 8 + xcd;
     if (bh >= nBH) return;
     const int h = bh % H, b = bh / H;
-    const int t0 = (wg * nT) / nWG, t1 = ((wg + 1) * nT) / nWG;        // up to 16 query tiles
+    // query tiles of this workgroup: full groups of 2 * nW first, the remainder in the last one, and wave w takes tiles 2w
+    // and 2w+1 -- at L = 197 (13 tiles, two 4-wave workgroups) that leaves ONE half-empty wave and one wave without tiles
+    // (it only helps staging K / V) instead of three half-empty ones whose second tile still cost a full softmax
+    const int tpw = 2 * ((int)blockDim.x >> 6);
+    const int t0 = wg * tpw, t1 = min(nT, t0 + tpw);
     const int nW = (int)blockDim.x >> 6;                               // waves: ceil(tiles per workgroup / 2)
     const half_t* base = qkv + (long)b * L * ld + h * 64;
 
@@ -51,7 +55,7 @@ __global__ __launch_bounds__(512, 4) void attn_f16_v1(const half_t* __restrict__
     half8_t qf[2][2];
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-        const int qt = t0 + wave + nW * u;
+        const int qt = t0 + 2 * wave + u;
         act[u] = qt < t1;
         qrow[u] = qt * 16 + fr;
         const int qc = min(qrow[u], L - 1);
@@ -105,7 +109,7 @@ __global__ __launch_bounds__(512, 4) void attn_f16_v1(const half_t* __restrict__
         // (16 KiB of fragment reads per (tile, block) against 16 MFMAs) and set the pace, not the matrix cores.
         bool on[2];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) on[u] = act[u] && !(CAUSAL && k0 > (t0 + wave + nW * u) * 16 + 15);   // wave-uniform
+        for (int u = 0; u < 2; ++u) on[u] = act[u] && !(CAUSAL && k0 > (t0 + 2 * wave + u) * 16 + 15);   // wave-uniform
         if (!on[0] && !on[1]) continue;
         // 16-key sub-tiles / 32-key halves of this block that hold any valid key (L = 197: the last block has 5 keys)
         const int nvalid = min(kmax - k0, KB1);
@@ -134,7 +138,7 @@ __global__ __launch_bounds__(512, 4) void attn_f16_v1(const half_t* __restrict__
             // raw-score maximum first (masking only in blocks that need it: the last key block, or the diagonal blocks of
             // the causal case), then p = exp2(fma(s, scale*log2e, -max*scale*log2e)): one VALU op less per element.
             // A tile that is switched off for this block sees every key masked: alpha = 1, p = 0, nothing changes.
-            const bool need_mask = !on[u] || (k0 + KB1 > L) || (CAUSAL && k0 + KB1 - 1 > (t0 + wave + nW * u) * 16);   // wave-uniform
+            const bool need_mask = !on[u] || (k0 + KB1 > L) || (CAUSAL && k0 + KB1 - 1 > (t0 + 2 * wave + u) * 16);   // wave-uniform
             float mx = -INFINITY;
             if (need_mask) {
 #pragma unroll
