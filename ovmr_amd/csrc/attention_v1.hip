@@ -115,20 +115,27 @@ __global__ __launch_bounds__(512, 4) void attn_f16_v1(const half_t* __restrict__
         const int nvalid = min(kmax - k0, KB1);
         const int ntv = (nvalid + 15) >> 4, nsv = (nvalid + 31) >> 5;
         float4_t s[2][4];
+        const float4_t zero = {0.f, 0.f, 0.f, 0.f};
+        auto s_tile = [&](int nt) {
+            const half8_t kf0 = *(const half8_t*)(sK + (nt * 16 + fr) * 64 + ((fg ^ (fr & 7)) << 3));
+            const half8_t kf1 = *(const half8_t*)(sK + (nt * 16 + fr) * 64 + (((4 + fg) ^ (fr & 7)) << 3));
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-            if (nt < ntv) {
-                const float4_t zero = {0.f, 0.f, 0.f, 0.f};
-                const half8_t kf0 = *(const half8_t*)(sK + (nt * 16 + fr) * 64 + ((fg ^ (fr & 7)) << 3));
-                const half8_t kf1 = *(const half8_t*)(sK + (nt * 16 + fr) * 64 + (((4 + fg) ^ (fr & 7)) << 3));
+            for (int u = 0; u < 2; ++u) {
+                s[u][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf0, qf[u][0], zero, 0, 0, 0);
+                s[u][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf1, qf[u][1], s[u][nt], 0, 0, 0);
+            }
+        };
+        if (ntv == 4) {          // complete key block (3 of 4 at L = 197): no accumulator zeroing in front of the MFMAs
 #pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    s[u][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf0, qf[u][0], zero, 0, 0, 0);
-                    s[u][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf1, qf[u][1], s[u][nt], 0, 0, 0);
+            for (int nt = 0; nt < 4; ++nt) s_tile(nt);
+        } else {
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                if (nt < ntv) s_tile(nt);
+                else {
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) s[u][nt] = zero;
                 }
-            } else {
-#pragma unroll
-                for (int u = 0; u < 2; ++u) s[u][nt] = (float4_t){0.f, 0.f, 0.f, 0.f};
             }
         }
         half8_t pf[2][2];
@@ -141,14 +148,13 @@ __global__ __launch_bounds__(512, 4) void attn_f16_v1(const half_t* __restrict__
             const bool need_mask = !on[u] || (k0 + KB1 > L) || (CAUSAL && k0 + KB1 - 1 > (t0 + 2 * wave + u) * 16);   // wave-uniform
             float mx = -INFINITY;
             if (need_mask) {
+                // keys of this lane are k0 + fg*4 + (nt*16 + r): valid while (nt*16 + r) < thr -- one compare against a
+                // constant and one select per element, no per-element key index
+                const int thr = (on[u] ? (CAUSAL ? min(L, q + 1) : L) : 0) - k0 - fg * 4;
 #pragma unroll
                 for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int key = k0 + nt * 16 + fg * 4 + r;
-                        const bool ok = on[u] && (key < L) && (!CAUSAL || key <= q);
-                        s[u][nt][r] = ok ? s[u][nt][r] : -INFINITY;
-                    }
+                    for (int r = 0; r < 4; ++r) s[u][nt][r] = (nt * 16 + r < thr) ? s[u][nt][r] : -INFINITY;
             }
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt)
