@@ -5,7 +5,8 @@
 //     through ds_read_b64_tr_b16: per 16-lane group the instruction reads 4 keys x 16 d and hands lane i
 //     the 4 keys of column d0+i -- exactly the V^T fragment (A operand of O^T = V^T P^T);
 //   * (r01g) the VALU issue port bounds this kernel (75 % busy against ~20 % for the MFMA pipe, tools/pmc_attn.sh): lazy
-//     rescaling against a reference maximum and row sums from the matrix pipe cut vector instructions (194 -> 183 us);
+//     rescaling against a reference maximum and row sums from the matrix pipe cut vector instructions (194 -> 183 us); tiles packed two per wave, no accumulator zeroing in complete key blocks and
+//     threshold-form masking (183 -> 167 us);
 //     a variant with a specialised body for complete unmasked key blocks spilled registers at the 128-VGPR cap and ran
 //     at 255 us -- not kept;
 //   * two 16-row query tiles per wave, 4 waves (8 tiles) per workgroup, both tiles of a wave sharing every K / V fragment
