@@ -12,10 +12,16 @@
 //   * residual rows (EPI_BIAS_RES) are requested before the accumulators are converted, not in front of each store;
 //   * large outputs are stored with the NONTEMPORAL hint (template bit 512): C then stops evicting the A / W panels the
 //     other tiles of the XCD are streaming out of its 4 MiB L2 (qkv 404 -> 368 us, c_fc 587 -> 556 us);
-//   * EPI_BIAS_RES can emit per-row partial (sum, sum of squares) for the LayerNorm that follows (common.h).
-// Measured and removed (profiles/r01e_gemm_experiments.md, r01g): L2 prefetch touches, staggered LDS-DMA issue, buffer_load
-// ... lds, s_setprio around the MFMA stream, a persistent one-workgroup-per-CU tile loop with the next tile's first K-tile
-// prefetched under the epilogue, W fragments straight from global memory, tile-contiguous C stores.
+//   * EPI_BIAS_RES can emit per-row partial (sum, sum of squares) for the LayerNorm that follows (common.h);
+//   * ONE workgroup barrier in the epilogue (the staging tiles are wave-private; the barriers that used to separate the
+//     phases also drained the first half's global stores), packed fp32 / fp16 VALU forms, interior tiles without bounds
+//     compares.
+// K loop variants chosen per launch (launch_v5): the A stream with the nontemporal policy for the residual projections
+// (OPT & 1), and the iteration boundary moved inside the MFMA stream (OPT & 4) for K >= 2048 and the LN-folding launches.
+// Measured and removed (profiles/r01e_gemm_experiments.md, r01g_gemm_epilogue.md): L2 prefetch touches (every workgroup, and
+// designated prefetcher workgroups), staggered LDS-DMA issue, buffer_load ... lds, s_setprio around the MFMA stream, a
+// persistent one-workgroup-per-CU tile loop with the next tile's first K-tile prefetched under the epilogue, W fragments
+// straight from global memory, tile-contiguous C stores, residual as accumulator start value, x ping-pong buffers.
 #include "common.h"
 
 #include <algorithm>
