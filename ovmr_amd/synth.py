@@ -219,12 +219,14 @@ def template_token_ids(context_length: int = CONTEXT_LENGTH) -> np.ndarray:
 
 
 def images(n: int, resolution: int, seed: int = 1234, class_ids: Optional[np.ndarray] = None,
-           class_strength: float = 0.0, start: int = 0) -> np.ndarray:
+           class_strength: float = 0.0, start: int = 0, tile: int = 0) -> np.ndarray:
     """[n,3,R,R] float32 ~ N(0,1) (post-normalisation statistics).
 
     With class_ids and class_strength > 0 each image is
-    sqrt(1-s^2)*noise + s*pattern[class], so exemplars of one class are correlated and the
-    cross-validation argmax has healthy margins (used by parity tests only).
+    sqrt(1-s^2)*noise + s*pattern[class], so exemplars of one class are correlated (used by parity tests only).
+    tile = 0: the class pattern is i.i.d. per pixel (a random-weight ViT averages it away: its features barely
+    depend on the class).  tile = t > 0: the class pattern is ONE [3,t,t] patch repeated over the image, which
+    survives the near-uniform attention of a random-weight ViT, so features of different classes separate.
     Image i depends only on (seed, start+i): shards can generate their own slice.
     """
     px = 3 * resolution * resolution
@@ -234,6 +236,32 @@ def images(n: int, resolution: int, seed: int = 1234, class_ids: Optional[np.nda
     if class_ids is not None and class_strength > 0.0:
         s = float(class_strength)
         for i in range(n):
-            pat = normal(f"pattern{int(class_ids[i])}", (px,), seed + 1)
+            if tile > 0:
+                reps = -(-resolution // tile)
+                pat = normal(f"tile{int(class_ids[i])}", (3, tile, tile), seed + 1)
+                pat = np.tile(pat, (1, reps, reps))[:, :resolution, :resolution].reshape(px)
+            else:
+                pat = normal(f"pattern{int(class_ids[i])}", (px,), seed + 1)
             out[i] = np.sqrt(1.0 - s * s) * out[i] + s * pat
     return out.reshape(n, 3, resolution, resolution)
+
+
+def align_state_dicts(sd: Dict[str, np.ndarray], pl: Dict[str, np.ndarray], spec: ModelSpec, gain: float) -> None:
+    """Give random-init weights the ONE property of trained OVMR weights the cross-validation step (K18-K20) relies on:
+    classifier rows that point towards their own class's image features.  In place, on fp32 state dicts:
+    an identity component `gain * I` is added to the value projection and to out_proj of every text-tower and aggregator
+    block and to text_projection, so attention copies (normalised) token content forward: visual tokens ~ mean exemplar
+    feature, the vision / multimodal classifier rows ~ the visual tokens.  Everything else stays random, so the
+    fixtures still exercise every parameter.  Needs transformer_width == embed_dim (true for every CLIP ViT)."""
+    T, E = spec.transformer_width, spec.embed_dim
+    assert T == E, "align_state_dicts needs transformer_width == embed_dim"
+    eye = np.eye(T, dtype=np.float32) * np.float32(gain)
+    for i in range(spec.transformer_layers):
+        p = f"transformer.resblocks.{i}."
+        sd[p + "attn.in_proj_weight"][2 * T:] += eye
+        sd[p + "attn.out_proj.weight"] += eye
+    sd["text_projection"] += eye
+    for i in range(spec.agg_layers):
+        p = f"aggregator.resblocks.{i}."
+        pl[p + "attn.in_proj_weight"][2 * E:] += eye
+        pl[p + "attn.out_proj.weight"] += eye

@@ -37,3 +37,30 @@ def golden():
     def load(name):
         return np.load(os.path.join(GOLDEN, name + ".npz"))
     return load
+
+
+def near_tie_classes(logits, margin):
+    """Classes whose cross-validation counters (tp, n_pred: trainers/mm_classifier_one_prompt.py:266-270) can differ
+    between two correct fp16 implementations: for every row whose runner-up lies within `margin` of the maximum, all
+    classes within `margin` of that maximum.  fusion_weight rows / fused-probability columns of every OTHER class must
+    agree with the reference exactly."""
+    logits = np.asarray(logits, dtype=np.float32)
+    cand = logits >= logits.max(1, keepdims=True) - margin
+    rows = cand.sum(1) > 1
+    return set(np.nonzero(cand[rows].any(0))[0].tolist())
+
+
+def aligned_case(g, name, tag="l2a", seed=11, n_ctx=2):
+    """Inputs of the `l2a` golden case (tests/golden/gen_golden.py:gen_l2_aligned), regenerated from the fixture's
+    metadata: aligned fp32 state dicts, exemplar images / labels, query images."""
+    from ovmr_amd import synth
+    spec = synth.SPECS[name]
+    sd = synth.clip_state_dict(spec, seed, jitter=True)
+    pl = synth.prompt_learner_state_dict(spec, n_ctx, seed, True)
+    synth.align_state_dicts(sd, pl, spec, float(g[f"{tag}_meta_gain"]))
+    labels, pattern = g[f"{tag}_eval_labels"], g[f"{tag}_eval_pattern_ids"]
+    s, tile = float(g[f"{tag}_meta_strength"]), int(g[f"{tag}_meta_tile"])
+    img = synth.images(len(labels), spec.image_resolution, seed=1234, class_ids=pattern, class_strength=s, tile=tile)
+    qlab = g[f"{tag}_query_labels"]
+    q = synth.images(len(qlab), spec.image_resolution, seed=777, class_ids=qlab, class_strength=s, tile=tile)
+    return spec, sd, pl, labels, img, qlab, q

@@ -114,6 +114,7 @@ def build_ref_clip(ref_model, spec, seed, jitter, fp32=False):
     return model.eval()
 
 
+ALIGNED_GAIN = {"small": 3.0, "vitb16": 1.5}     # synth.align_state_dicts gain of the l2a fixtures
 CLASSNAMES = ["accordion", "bass guitar", "airplane", "sea_horse", "stop sign", "yin yang"]
 
 
@@ -213,6 +214,111 @@ def gen_l2(ref_model, ref_clip, ref_l2, spec, seed, n_ctx, shots, tau, classes_p
         out[f"{tag}_state_dict_keys"] = np.array(sorted(model.prompt_learner.state_dict().keys()))
 
 
+# ----------------------------------------------------------------------------- L2 vectors, "aligned" weights
+# With plain random weights the classifier rows are unrelated to the image features, every cross-validation argmax
+# (trainers/mm_classifier_one_prompt.py:266-270) is decided by noise, and some of them by less than one fp16 step --
+# a comparison of fusion_weight with another implementation is then ill-posed.  The "l2a" fixtures use
+#   * synth.align_state_dicts (an identity component in the value / output projections of the text tower and the
+#     aggregator, so classifier rows point towards their own class's image features, as trained OVMR weights do),
+#   * tiled class patterns at strength 0.9 (features of different classes separate),
+#   * 12 classes x 8 shots, a few exemplars per class carrying the NEXT class's pattern (clear-margin mistakes, so
+#     tp / n_pred / F1 differ from class to class),
+#   * class names chosen from NAME_POOL so that the zero-shot text classifier's argmax is clear on every row:
+#     one name wins everywhere by > TEXT_GAP, the other eleven are the pool's lowest-scoring names.
+# The script asserts that EVERY cross-validation row of the reference has a top-2 margin > MARGIN for all three classifiers,
+# so tests compare fusion_weight / logits_fusion with these fixtures unconditionally.
+NAME_POOL = ["accordion", "bass guitar", "airplane", "sea_horse", "stop sign", "yin yang", "tench", "goldfish",
+             "hammerhead shark", "electric ray", "hen", "ostrich", "bulbul", "jay", "magpie", "water ouzel", "kite",
+             "bald eagle", "great grey owl", "fire salamander", "bullfrog", "tree frog", "loggerhead", "mud turtle",
+             "banded gecko", "green lizard", "komodo dragon", "african crocodile", "triceratops", "thunder snake",
+             "garter snake", "sea snake", "trilobite", "scorpion", "garden spider", "tick", "centipede", "black grouse",
+             "peacock", "quail", "macaw", "drake", "goose", "black swan", "wombat", "jellyfish", "sea anemone", "flatworm"]
+MARGIN, TEXT_GAP = 0.5, 0.75
+
+
+def aligned_inputs(spec, C, shots, n_query, strength, tile):
+    """Labels, pattern ids (a class's last c % 3 shots carry the next class's pattern) and images of the l2a case."""
+    order = np.random.default_rng(5).permutation(C).astype(np.int64)
+    labels = np.repeat(order, shots)
+    pattern = labels.copy()
+    for i, c in enumerate(order):
+        m = int(c) % 3
+        if m:
+            pattern[(i + 1) * shots - m:(i + 1) * shots] = (int(c) + 1) % C
+    img = synth.images(C * shots, spec.image_resolution, seed=1234, class_ids=pattern, class_strength=strength, tile=tile)
+    qlab = np.arange(n_query, dtype=np.int64) % C
+    q = synth.images(n_query, spec.image_resolution, seed=777, class_ids=qlab, class_strength=strength, tile=tile)
+    return labels, pattern, img, qlab, q
+
+
+@torch.no_grad()
+def gen_l2_aligned(ref_model, ref_l2, spec, seed, gain, out, tag="l2a", C=12, shots=8, cpb=4, n_query=8,
+                   strength=0.9, tile=16, tau=3.0, n_ctx=2):
+    sd_np = synth.clip_state_dict(spec, seed, jitter=True)
+    pl_np = synth.prompt_learner_state_dict(spec, n_ctx, seed, True)
+    synth.align_state_dicts(sd_np, pl_np, spec, gain)
+    clip_model = ref_model.build_model({k: torch.from_numpy(v) for k, v in sd_np.items()}).eval()
+    pl_sd = {k: torch.from_numpy(v) for k, v in pl_np.items()}
+    labels, pattern, img, qlab, q = aligned_inputs(spec, C, shots, n_query, strength, tile)
+    ls = clip_model.logit_scale.exp()
+
+    # pass 1: choose the class names.  Text rows of the whole pool against the exemplar features.
+    with tempfile.TemporaryDirectory() as outdir:
+        pool = ref_l2.CustomCLIP(make_cfg(n_ctx, shots, tau, "fusion", outdir), NAME_POOL, clip_model).eval()
+        f = pool.image_encoder(torch.from_numpy(img).half())
+        f = f / f.norm(dim=-1, keepdim=True)
+        lg = (ls * f @ pool.zero_shot_classifier.t()).float().numpy()          # [C*S, pool]
+    win = int(lg.mean(0).argmax())
+    ok = [j for j in range(len(NAME_POOL)) if j != win and (lg[:, win] - lg[:, j]).min() > TEXT_GAP]
+    assert len(ok) >= C - 1, f"only {len(ok)} pool names stay {TEXT_GAP} below the winner on every row"
+    ok = sorted(ok, key=lambda j: lg[:, j].max())[:C - 1]
+    names = [NAME_POOL[j] for j in sorted(ok)]
+    names.insert(7, NAME_POOL[win])
+    out[f"{tag}_classnames"] = np.array(names)
+
+    # pass 2: the generation job itself
+    with tempfile.TemporaryDirectory() as outdir:
+        cfg = make_cfg(n_ctx, shots, tau, "fusion", outdir)
+        model = ref_l2.CustomCLIP(cfg, names, clip_model).eval()
+        model.prompt_learner.load_state_dict(pl_sd, strict=True)
+        model.device = torch.device("cpu")
+        out[f"{tag}_tokenized_prompts"] = model.tokenized_prompts.numpy()
+        out[f"{tag}_eval_labels"] = labels
+        out[f"{tag}_eval_pattern_ids"] = pattern
+        out[f"{tag}_query_labels"] = qlab
+        step = cpb * shots
+        loader = [{"img": torch.from_numpy(img[s:s + step]), "label": torch.from_numpy(labels[s:s + step])}
+                  for s in range(0, C * shots, step)]
+        qt = torch.from_numpy(q)
+        for mode in ("fusion", "text", "vision", "multimodal"):
+            cfg.EVAL_MODE = mode
+            out[f"{tag}_logits_{mode}"] = model(qt, eval_set_loader=loader).float().numpy()
+        saved = torch.load(os.path.join(outdir, "mm_classifiers.pt"))
+        for k, v in saved.items():
+            out[f"{tag}_saved_{k}"] = v.numpy()
+        out[f"{tag}_saved_visual_tokens"] = torch.load(os.path.join(outdir, "visual_tokens.pt"))["visual_tokens"].float().numpy()
+        out[f"{tag}_eval_feat4cls"] = model.eval_feat4cls.float().numpy()
+    for k, v in (("gain", gain), ("shots", shots), ("classes_per_batch", cpb), ("tau", tau), ("strength", strength),
+                 ("tile", tile), ("margin", MARGIN)):
+        out[f"{tag}_meta_{k}"] = np.array(v)
+
+    # the fixture's contract: every argmax of the reference is clear
+    rows = torch.from_numpy(out[f"{tag}_eval_feat4cls"]).half()
+    stats = {}
+    for k in ("mm_classifier", "vision_classifier", "text_classifier"):
+        l3 = (ls * torch.einsum("bmc,pc->bmp", rows, torch.from_numpy(out[f"{tag}_saved_{k}"]).half())).flatten(0, 1).float().numpy()
+        srt = np.sort(l3, axis=1)
+        margin = srt[:, -1] - srt[:, -2]
+        acc = float((l3.argmax(1) == np.repeat(np.arange(C), shots)).mean())
+        stats[k] = (float(margin.min()), acc)
+        assert margin.min() > MARGIN, f"{tag} {k}: top-2 margin {margin.min():.3f} <= {MARGIN}"
+    qm = {}
+    for mode, k in (("multimodal", "mm_classifier"), ("vision", "vision_classifier"), ("text", "text_classifier")):
+        qf = out[f"{tag}_logits_{mode}"]
+        qm[mode] = float(np.sort(qf, axis=1)[:, -1].min())
+    print(f"{tag} {spec.name}: names {names}\n   (min margin, accuracy) {stats}\n   fusion_weight\n{np.round(out[tag + '_saved_fusion_weight'], 3)}")
+
+
 def gen_tokenizer(ref_clip, out):
     names = ["a .", "a accordion.", "a bass guitar.", "a sea horse.", "a photo of a yin yang.",
              "a great white shark.", "a toilet tissue.", "a hen-of-the-woods.", "a jack-o'-lantern.", "a T-shirt.",
@@ -250,6 +356,8 @@ def main():
         gen_l2(ref_model, ref_clip, ref_l2, spec, 11, 2, shots, 10.0, cpb, nq, out, "l2")
         if key != "vitb16":
             gen_l2(ref_model, ref_clip, ref_l2, spec, 11, 1, shots, 10.0, cpb, nq, out, "l2n1")
+        if key in ALIGNED_GAIN:
+            gen_l2_aligned(ref_model, ref_l2, spec, 11, ALIGNED_GAIN[key], out)
         # fp16-valued tensors are stored as float16 (lossless, checked); everything else as produced
         store = {}
         for k, v in out.items():
