@@ -177,8 +177,10 @@ class PromptLearner:
 
         self.prompt_tokens = e.embed_tokens(self.tokenized_prompts)                 # :129,131
         self.visual_prompt_temp = e.embed_tokens(vt.to(dev))                        # :130
+        # :118-126.  The reference skips this for num_class >= 5000 and then fails at :265 ("limits the
+        # build must lift"); here such vocabularies get their text rows batch by batch inside forward_prompt instead.
         self.zero_shot_classifier = None
-        if compute_zero_shot and self.num_class < 5000:                             # :118
+        if compute_zero_shot and self.num_class < 5000:
             self.zero_shot_classifier = self.encode_zero_shot(self.tokenized_prompts)
 
     def encode_zero_shot(self, tokenized: torch.Tensor) -> torch.Tensor:
@@ -309,7 +311,11 @@ class CustomCLIP:
         self.inference_text_initialized = torch.zeros(C, dtype=torch.int32, device=dev)
         self.visual_tokens = torch.ones((C, n_ctx, D), **f16)
         self.eval_feat4cls = torch.zeros((C, S, D), **f16)
-        text_clf = self.zero_shot_classifier if self.zero_shot_classifier is not None else torch.zeros((C, D), **f16)
+        # text rows: precomputed by PromptLearner.__init__ (:118-126) for < 5000 classes in one process; otherwise
+        # (large vocabularies, or class-sharded ranks) each exemplar batch encodes the prompts of its own classes
+        streamed_text = pl.zero_shot_classifier is None or getattr(self, "_text_streamed", False)
+        self._text_streamed = streamed_text
+        text_clf = torch.zeros((C, D), **f16) if streamed_text else self.zero_shot_classifier
         local_labels = []
         presharded = bool(getattr(eval_set_loader, "presharded", False))
         for batch_idx, batch in enumerate(eval_set_loader):
@@ -327,7 +333,7 @@ class CustomCLIP:
             self.visual_classifer[exemplar_label] = v                               # :252
             self.inference_text_initialized[exemplar_label] = 1                     # :254
             self.visual_tokens[exemplar_label] = tokens.half()                      # :255
-            if dist:
+            if streamed_text:
                 text_clf[exemplar_label] = pl.encode_zero_shot(self.tokenized_prompts[exemplar_label])
             local_labels.append(exemplar_label)
         local = torch.cat(local_labels) if local_labels else torch.zeros(0, dtype=torch.long, device=dev)
@@ -343,6 +349,7 @@ class CustomCLIP:
             text_clf[labels] = rows[:, 2 * D:3 * D]
             self.visual_tokens[labels] = rows[:, 3 * D:].reshape(-1, n_ctx, D)
             self.inference_text_initialized[labels] = 1
+        if streamed_text:
             self.zero_shot_classifier = self.prompt_learner.zero_shot_classifier = text_clf
         assert bool(self.inference_text_initialized.bool().all()), "a class received no exemplar batch"   # :259
 

@@ -1,0 +1,243 @@
+"""BASELINE.json configurations on the HIP path (`pytest -m gpu`), each against the CPU oracle:
+
+  headline  ViT-B/16, 1000 classes x 16 shots + queries: the exact job bench.py times (device-generated weights),
+            sampled classes / queries against the oracle, ALL argmax counters against a CPU restatement;
+  c4        a vocabulary of >= 5000 classes in ONE process (the reference leaves zero_shot_classifier = None at
+            trainers/mm_classifier_one_prompt.py:118 and then fails at :265), cross-validation logits streamed in
+            several workspace chunks;
+  c5        the classifier-generation head at embed_dim = transformer_width = 768 (ViT-L/14 text side: 12 heads,
+            fp32 aggregator 768 wide) through generation and the four EVAL_MODEs.
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import COS_TOL, assert_cosine, near_tie_classes
+from ovmr_amd import synth
+
+pytestmark = pytest.mark.gpu
+SEED = 11
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import ovmr_oracle
+    return ovmr_oracle
+
+
+def _count_bounds(logits, row_labels, C, margin):
+    """[lo, hi] for tp and n_pred of every class when an argmax may land on any class within `margin` of the row maximum."""
+    top = logits.max(1, keepdims=True)
+    cand = logits >= top - margin
+    sure = cand.sum(1) == 1
+    pred = logits.argmax(1)
+    n_lo = np.bincount(pred[sure], minlength=C)
+    n_hi = n_lo + cand[~sure].sum(0)
+    own = cand[np.arange(len(row_labels)), row_labels]
+    tp_lo = np.bincount(row_labels[sure & own], minlength=C)
+    tp_hi = tp_lo + np.bincount(row_labels[~sure & own], minlength=C)
+    return tp_lo, tp_hi, n_lo, n_hi
+
+
+def _fp16_logits(feats, clf, scale):
+    """h(h(f . c) * scale): the reference's fp16 einsum followed by the 0-dim fp32 scale (:263-265), from fp32 sums."""
+    return ((feats.float() @ clf.float().t()).half().float() * scale).half().float().numpy()
+
+
+@pytest.mark.timeout(1800)
+def test_headline_config_bench_job_vs_oracle(O):
+    """The job bench.py times -- ViT-B/16, 1000 classes x 16 shots, weights drawn on the device exactly as bench.py
+    draws them -- through CustomCLIP.forward_prompt on the HIP path, then
+      * 4 sampled classes: image features, multimodal / vision / text classifier rows and visual tokens against the oracle
+        (64 images + 12 prompts of CPU work),
+      * ALL 3 x 2 x 1000 argmax counters against a CPU restatement on the same fp16 features / classifier rows
+        (an argmax may land on any class within 2 fp16 steps of the row maximum: bounds per counter),
+      * fusion weights = softmax(tau * F1(counters)) exactly,
+      * 8 query rows of the fused output against the oracle."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    from ovmr_amd import modules
+    from ovmr_amd.data import ResidentEvalSet
+    dev = torch.device("cuda:0")
+    spec, C, S, n_ctx, batch = synth.SPECS["ViT-B/16"], 1000, 16, 2, 512
+    gen = torch.Generator(device=dev).manual_seed(1234)
+    sd = bench.device_clip_state(spec, gen, dev)
+    pl = bench.device_pl_state(spec, n_ctx, gen, dev)
+    cm = modules.CLIPModel(sd, spec, str(dev))
+    cfg = modules.make_cfg(n_ctx=n_ctx, num_shots=S, eval_mode="fusion", eval_tau=10.0, output_dir="", test_batch_size=batch)
+    tok = torch.from_numpy(synth.class_token_ids(C, seed=4321))
+    model = modules.CustomCLIP(cfg, tok, cm, prompt_learner_state=pl, reserve=(batch, 1024, 1024))
+    ig = torch.Generator(device=dev).manual_seed(1234)
+    R = spec.image_resolution
+    ex = torch.empty((C * S, 3, R, R), dtype=torch.float16, device=dev)
+    for s in range(0, C * S, 1024):
+        ex[s:s + 1024] = torch.randn((min(1024, C * S - s), 3, R, R), generator=ig, device=dev).half()
+    q = torch.randn((8, 3, R, R), generator=ig, device=dev).half()
+    loader = ResidentEvalSet(ex, torch.arange(C, device=dev), S, 256, presharded=True)
+    mm, v, fw = model.forward_prompt(loader)
+    out = model(q).cpu()
+    t = model.zero_shot_classifier
+    feats = model.eval_feat4cls
+    assert bool(torch.isfinite(mm.float()).all() and torch.isfinite(v.float()).all() and torch.isfinite(fw).all())
+
+    # ---- sampled classes against the oracle (CPU, fp16 like the reference)
+    cpu_sd = O.convert_weights({k: x.detach().float().cpu() for k, x in sd.items()}, "fp16")
+    cpu_pl = {k: x.detach().float().cpu() for k, x in pl.items()}
+    sample = [0, 333, 642, 999]
+    torch.set_num_threads(min(32, os.cpu_count()))
+    rows = torch.cat([ex[c * S:(c + 1) * S] for c in sample]).cpu()
+    with torch.no_grad():
+        r = O.forward_prompt(rows, torch.arange(len(sample)).repeat_interleave(S), tok[sample], cpu_sd, cpu_pl, n_ctx, 10.0,
+                             len(sample), "fp16")
+        qf = O.l2_normalize(O.encode_image(q.cpu(), cpu_sd))
+    assert_cosine(feats[sample].flatten(0, 1).float().cpu().numpy(), r["eval_feat4cls"].flatten(0, 1).float().numpy(), COS_TOL, "eval_feat4cls")
+    assert_cosine(mm[sample].float().cpu().numpy(), r["mm_classifier"].numpy(), COS_TOL, "mm rows")
+    assert_cosine(v[sample].float().cpu().numpy(), r["vision_classifier"].numpy(), COS_TOL, "vision rows")
+    assert_cosine(t[sample].float().cpu().numpy(), r["text_classifier"].numpy(), COS_TOL, "text rows")
+    assert_cosine(model.visual_tokens[sample].float().cpu().numpy(), r["visual_tokens"].float().numpy(), COS_TOL, "visual tokens")
+
+    # ---- every counter of the cross-validation step, on the job's own fp16 features and classifier rows
+    counts = model.xval_counts.cpu().numpy()
+    f_cpu = feats.flatten(0, 1).cpu()
+    row_lab = np.repeat(np.arange(C), S)
+    ls = float(model.engine.logit_scale)
+    for m, clf in enumerate((mm, v, t)):
+        lg = _fp16_logits(f_cpu, clf.cpu(), ls)
+        tp_lo, tp_hi, n_lo, n_hi = _count_bounds(lg, row_lab, C, 0.13)
+        assert counts[m, 1].sum() == C * S
+        assert ((counts[m, 0] >= tp_lo) & (counts[m, 0] <= tp_hi)).all(), f"tp of classifier {m}"
+        assert ((counts[m, 1] >= n_lo) & (counts[m, 1] <= n_hi)).all(), f"n_pred of classifier {m}"
+    f1 = torch.stack([O.f1_from_counts(torch.from_numpy(counts[m, 0]), torch.from_numpy(counts[m, 1]), torch.full((C,), S))
+                      for m in range(3)], -1)
+    np.testing.assert_allclose(fw.cpu().numpy(), (10.0 * f1).softmax(-1).numpy(), atol=1e-6)
+
+    # ---- fused query rows: oracle features, the job's classifiers and weights
+    ref = O.inference_logits(qf, mm.cpu(), v.cpu(), t.cpu(), fw.cpu(), torch.tensor(ls), "fusion")
+    assert out.shape == (8, C)
+    assert_cosine(out.numpy(), ref.numpy(), COS_TOL, "fused query rows")
+    del model, cm, ex
+    torch.cuda.empty_cache()
+
+
+def _small_clip(name, gain=0.0):
+    from ovmr_amd import modules
+    spec = synth.SPECS[name]
+    sd = synth.clip_state_dict(spec, SEED, jitter=True)
+    pl = synth.prompt_learner_state_dict(spec, 2, SEED, True)
+    if gain:
+        synth.align_state_dicts(sd, pl, spec, gain)
+    cm = modules.CLIPModel({k: torch.from_numpy(x) for k, x in sd.items()}, spec)
+    return spec, sd, pl, cm
+
+
+@pytest.mark.timeout(1800)
+def test_config_c4_six_thousand_classes_single_process(O, tmp_path):
+    """C = 6000 >= 5000 in one process on the tiny model, 2 shots: the text rows are encoded batch by batch (the reference
+    cannot run this at all), the cross-validation logits [12000, 6000] = 72 M elements stream through the 32 M-element
+    workspace in three chunks.  Classifier rows against the oracle on sampled classes; all counters against the CPU
+    restatement and against the same kernel fed 1000 rows at a time (chunk-boundary independence)."""
+    from ovmr_amd import modules
+    spec, sd, pl, cm = _small_clip("tiny")
+    C, S, cpb = 6000, 2, 500
+    tok = torch.from_numpy(synth.class_token_ids(C, seed=77))
+    cfg = modules.make_cfg(n_ctx=2, num_shots=S, output_dir=str(tmp_path))
+    model = modules.CustomCLIP(cfg, tok, cm, prompt_learner_state={k: torch.from_numpy(x) for k, x in pl.items()},
+                               reserve=(1024, 1024, 1024))
+    assert model.zero_shot_classifier is None                       # :118 -- lifted inside forward_prompt
+    g = torch.Generator().manual_seed(9)
+    order = torch.randperm(C, generator=g)
+    labels = order.repeat_interleave(S)
+    pat = torch.randn((C, 3, 32, 32), generator=g)
+    img = 0.6 * torch.randn((C * S, 3, 32, 32), generator=g) + 0.8 * pat[labels]
+    loader = [{"img": img[s:s + cpb * S], "label": labels[s:s + cpb * S]} for s in range(0, C * S, cpb * S)]
+    mm, v, fw = model.forward_prompt(loader)
+    t = model.zero_shot_classifier
+    assert t is not None and t.shape == (C, spec.embed_dim) and fw.shape == (C, 3)
+    saved = torch.load(os.path.join(str(tmp_path), "mm_classifiers.pt"), map_location="cpu")
+    assert saved["text_classifier"].shape == (C, spec.embed_dim) and saved["text_classifier"].dtype == torch.float32
+
+    sample = torch.tensor([0, 17, 2999, 4999, 5000, 5999])
+    cpu_sd = O.convert_weights(O.to_torch(sd), "fp16")
+    rows = torch.cat([img[(labels == c)] for c in sample.tolist()])
+    with torch.no_grad():
+        r = O.forward_prompt(rows, torch.arange(len(sample)).repeat_interleave(S), tok[sample], cpu_sd, O.to_torch(pl), 2, 10.0,
+                             len(sample), "fp16")
+    assert_cosine(mm[sample].float().cpu().numpy(), r["mm_classifier"].numpy(), COS_TOL, "mm rows")
+    assert_cosine(v[sample].float().cpu().numpy(), r["vision_classifier"].numpy(), COS_TOL, "vision rows")
+    assert_cosine(t[sample].float().cpu().numpy(), r["text_classifier"].numpy(), COS_TOL, "text rows")
+
+    counts = model.xval_counts.cpu().numpy()
+    feats = model.eval_feat4cls.flatten(0, 1)
+    row_lab_t = torch.arange(C, dtype=torch.int32).repeat_interleave(S)
+    row_lab = row_lab_t.numpy()
+    ls = float(model.engine.logit_scale)
+    for m, clf in enumerate((mm, v, t)):
+        lg = _fp16_logits(feats.cpu(), clf.cpu(), ls)
+        tp_lo, tp_hi, n_lo, n_hi = _count_bounds(lg, row_lab, C, 0.13)
+        assert counts[m, 1].sum() == C * S
+        assert ((counts[m, 0] >= tp_lo) & (counts[m, 0] <= tp_hi)).all(), f"tp of classifier {m}"
+        assert ((counts[m, 1] >= n_lo) & (counts[m, 1] <= n_hi)).all(), f"n_pred of classifier {m}"
+        # the same rows 1000 at a time: identical counters
+        again = torch.zeros((2, C), dtype=torch.int32, device="cuda")
+        for r0 in range(0, C * S, 1000):
+            model.engine.xval_counts(feats[r0:r0 + 1000], row_lab_t[r0:r0 + 1000], clf, again[0], again[1])
+        np.testing.assert_array_equal(again.cpu().numpy(), counts[m])
+    f1 = torch.stack([O.f1_from_counts(torch.from_numpy(counts[m, 0]), torch.from_numpy(counts[m, 1]), torch.full((C,), S))
+                      for m in range(3)], -1)
+    np.testing.assert_allclose(fw.cpu().numpy(), (10.0 * f1).softmax(-1).numpy(), atol=1e-6)
+    # fused inference at C = 6000 against the oracle on the job's own classifiers
+    q = img[:5]
+    out = model(q).cpu()
+    with torch.no_grad():
+        qf = O.l2_normalize(O.encode_image(q.half(), cpu_sd))
+    ref = O.inference_logits(qf, mm.cpu(), v.cpu(), t.cpu(), fw.cpu(), torch.tensor(ls), "fusion")
+    assert_cosine(out.numpy(), ref.numpy(), COS_TOL, "fused rows at C = 6000")
+
+
+def test_config_c5_head_at_width_768(O, tmp_path):
+    """embed_dim = transformer_width = 768 (the ViT-L/14 head: 12 text heads, fp32 aggregator 768 wide with 12 heads,
+    prompts assembled at width 768, cross-validation / fused logits at K = 768) on a 2-layer model: generation and the
+    four EVAL_MODEs against the oracle, 12 classes x 32 shots (config 5's shot count: aggregator sequence 34)."""
+    from ovmr_amd import modules
+    spec, sd, pl, cm = _small_clip("head768", gain=3.0)
+    C, S, cpb, tau = 12, 32, 5, 3.0
+    tok = torch.from_numpy(synth.class_token_ids(C, seed=5))      # seed picked (offline, with the oracle) for clear text argmaxes
+    cfg = modules.make_cfg(n_ctx=2, num_shots=S, eval_tau=tau, output_dir=str(tmp_path))
+    model = modules.CustomCLIP(cfg, tok, cm, prompt_learner_state={k: torch.from_numpy(x) for k, x in pl.items()},
+                               reserve=(256, 64, 64))
+    labels = np.repeat(np.random.default_rng(5).permutation(C), S)
+    img = torch.from_numpy(synth.images(C * S, spec.image_resolution, 1234, labels, 0.9, tile=16))
+    qlab = np.arange(8) % C
+    q = torch.from_numpy(synth.images(8, spec.image_resolution, 777, qlab, 0.9, tile=16))
+    loader = [{"img": img[s:s + cpb * S], "label": torch.from_numpy(labels[s:s + cpb * S])} for s in range(0, C * S, cpb * S)]
+    outs = {}
+    for mode in ("fusion", "text", "vision", "multimodal"):
+        cfg.EVAL_MODE = mode
+        outs[mode] = model(q, eval_set_loader=loader).cpu()
+    cpu_sd = O.convert_weights(O.to_torch(sd), "fp16")
+    with torch.no_grad():
+        r = O.forward_prompt(img, torch.from_numpy(labels), tok, cpu_sd, O.to_torch(pl), 2, tau, cpb, "fp16")
+        qf = O.l2_normalize(O.encode_image(q.half(), cpu_sd))
+    assert_cosine(model.eval_feat4cls.float().cpu().numpy(), r["eval_feat4cls"].float().numpy(), COS_TOL, "eval_feat4cls")
+    np.testing.assert_allclose(model.visual_tokens.float().cpu().numpy(), r["visual_tokens"].float().numpy(), atol=2e-2, rtol=2e-2)
+    assert_cosine(model.visual_tokens.float().cpu().numpy(), r["visual_tokens"].float().numpy(), COS_TOL, "visual tokens")
+    assert_cosine(model.mm_classifier.float().cpu().numpy(), r["mm_classifier"].numpy(), COS_TOL, "mm")
+    assert_cosine(model.visual_classifer.float().cpu().numpy(), r["vision_classifier"].numpy(), COS_TOL, "vision")
+    assert_cosine(model.zero_shot_classifier.float().cpu().numpy(), r["text_classifier"].numpy(), COS_TOL, "text")
+    ls = cpu_sd["logit_scale"].float().exp()
+    affected = set()
+    for k in ("mm_classifier", "vision_classifier", "text_classifier"):
+        affected |= near_tie_classes(O.cross_validation_logits(r["eval_feat4cls"], r[k].half(), ls).float().numpy(), 0.26)
+    ok = np.array([c not in affected for c in range(C)])
+    assert ok.sum() >= C - 3, f"only {int(ok.sum())} classes free of near-ties"
+    np.testing.assert_allclose(model.fusion_weight.cpu().numpy()[ok], r["fusion_weight"].numpy()[ok], atol=1e-5)
+    for mode in ("text", "vision", "multimodal"):
+        ref = O.inference_logits(qf, r["mm_classifier"].half(), r["vision_classifier"].half(), r["text_classifier"].half(),
+                                 r["fusion_weight"], ls, mode)
+        assert_cosine(outs[mode].numpy(), ref.numpy(), COS_TOL, mode)
+    ref = O.inference_logits(qf, r["mm_classifier"].half(), r["vision_classifier"].half(), r["text_classifier"].half(),
+                             r["fusion_weight"], ls, "fusion")
+    assert_cosine(outs["fusion"].numpy()[:, ok], ref.numpy()[:, ok], COS_TOL, "fusion (classes free of near-ties)")
