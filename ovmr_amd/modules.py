@@ -8,9 +8,9 @@ nothing falls back when the HIP library or the GPU is missing.
 
 Differences a reference user will notice (all documented in DESIGN.md):
   * `clip_model` is a `CLIPModel` (weights + architecture), not an nn.Module;
-  * class names need a tokenizer: pass `tokenizer=` (an object with the reference
-    SimpleTokenizer's `encode(str) -> list[int]`) or pass already tokenised prompts
-    (LongTensor [C, 77]) in place of `classnames`;
+  * class names are tokenised with the CLIP merge table named by OVMR_BPE_PATH (or ./clip/bpe_simple_vocab_16e6.txt.gz);
+    `tokenizer=` (an object with the reference SimpleTokenizer's `encode(str) -> list[int]`) or already tokenised
+    prompts (LongTensor [C, 77]) in place of `classnames` are accepted too;
   * the training branch of CustomCLIP.forward (:310-338) is out of scope and raises;
   * with torch.distributed initialised, forward_prompt shards the eval-set batches over ranks,
     all-gathers the classifier rows (RCCL) and all-reduces the F1 counters.
@@ -108,6 +108,22 @@ def make_cfg(n_ctx: int = 2, num_shots: int = 16, eval_mode: str = "fusion", eva
         EVAL_MODE=eval_mode, EVAL_TAU=eval_tau, OUTPUT_DIR=output_dir, SEED=1)
 
 
+_DEFAULT_TOKENIZER = {}
+
+
+def default_tokenizer():
+    """BPETokenizer on the CLIP merge table named by OVMR_BPE_PATH, or found at ./clip/bpe_simple_vocab_16e6.txt.gz (the
+    working directory of a reference checkout).  FileNotFoundError when neither exists: the table is not shipped here."""
+    from .tokenizer import BPETokenizer
+    path = os.environ.get("OVMR_BPE_PATH") or osp.join("clip", "bpe_simple_vocab_16e6.txt.gz")
+    if path not in _DEFAULT_TOKENIZER:
+        if not osp.exists(path):
+            raise FileNotFoundError("class names need the CLIP BPE merge table: set OVMR_BPE_PATH to bpe_simple_vocab_16e6.txt.gz "
+                                    "(it is in every CLIP checkout), pass tokenizer=, or pass tokenised prompts [C,77] instead of names")
+        _DEFAULT_TOKENIZER[path] = BPETokenizer(path)
+    return _DEFAULT_TOKENIZER[path]
+
+
 def tokenize(texts: Sequence[str], tokenizer, context_length: int = 77) -> torch.Tensor:
     """clip.tokenize (clip/clip.py:187-223) on top of a caller-supplied BPE `tokenizer.encode`."""
     out = torch.zeros(len(texts), context_length, dtype=torch.long)
@@ -155,8 +171,9 @@ class PromptLearner:
             self.name_lens = (tokenized.argmax(-1) - 3).tolist()
         else:
             if tokenizer is None:
-                raise ValueError("class names need `tokenizer=` (reference SimpleTokenizer-compatible encode()); "
-                                 "alternatively pass tokenised prompts [C,77] instead of names")
+                # the reference's module-level `_tokenizer = _Tokenizer()` (:26) reads the merge table that sits next to
+                # clip/simple_tokenizer.py; here it comes from OVMR_BPE_PATH or ./clip/bpe_simple_vocab_16e6.txt.gz
+                tokenizer = default_tokenizer()
             names = [n.replace("_", " ") for n in classnames]                       # :109
             self.name_lens = [len(tokenizer.encode(n)) for n in names]              # :110
             tokenized = tokenize(["a " + n + "." for n in names], tokenizer, spec.context_length)   # :113,116

@@ -72,6 +72,8 @@ SPECS: Dict[str, ModelSpec] = {
     # parity-test sizes (all intermediates cheap on CPU)
     "tiny": ModelSpec("tiny", 128, 32, 2, 128, 16, 77, 49408, 128, 2, 2),
     "small": ModelSpec("small", 256, 64, 3, 256, 16, 77, 49408, 256, 4, 3),
+    # checkpoint-format fixtures (tests/golden/gen_checkpoints.py): small enough to commit as a TorchScript archive
+    "micro": ModelSpec("micro", 64, 32, 1, 64, 16, 77, 512, 64, 1, 1),
     # the ViT-L/14 HEAD (embed_dim = text width = 768, 12 text heads, 768-wide aggregator) behind a 2-layer vision tower
     "head768": ModelSpec("head768", 768, 64, 2, 256, 16, 77, 49408, 768, 12, 2),
 }

@@ -563,3 +563,72 @@ def test_entry_points_are_graph_capturable():
     got = out.clone()
     ref = e.fused_logits(e.encode_image(img, normalize=True), clf[0], clf[1], clf[2], w, "fusion")
     assert torch.equal(got, ref)
+
+
+def test_reference_written_checkpoints_on_the_engine():
+    """the TorchScript CLIP archive and the Dassl checkpoint directory written by the reference's own code
+    (tests/golden/gen_checkpoints.py) -> ovmr_amd.checkpoint -> engine; image / text features against the outputs the
+    reference's CLIP module produced from the same archive."""
+    from ovmr_amd import checkpoint, modules
+    ck = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ckpt")
+    exp = np.load(os.path.join(ck, "micro_expected.npz"))
+    cm = modules.build_model(checkpoint.load_clip_state_dict(os.path.join(ck, "micro_clip_jit.pt")))
+    assert cm.spec.vocab_size == 512 and cm.spec.vision_width == 64
+    e = cm.engine(2)
+    e.load_state_dict({}, checkpoint.load_prompt_learner_state(ck, 30))
+    e._pl_loaded = True
+    e.finalize(8, 8, 8)
+    img = torch.from_numpy(synth.images(3, 32, seed=21))
+    assert_cosine(e.encode_image(img, normalize=False).float().cpu().numpy(), exp["image_features"], COS_TOL, "image features")
+    ids = torch.from_numpy(exp["text_ids"])
+    assert_cosine(e.encode_text_ids(ids, normalize=0).float().cpu().numpy(), exp["text_features"], COS_TOL, "text features")
+    tokens = e.generate_tokens(torch.nn.functional.normalize(torch.randn(2, 4, 64), dim=-1).half())
+    assert tokens.shape == (2, 2, 64) and bool(torch.isfinite(tokens).all())
+
+
+def test_mm_cls_op_trainer_shim(tmp_path, O, monkeypatch):
+    """trainer name MM_CLS_OP with build_model / load_model / parse_batch_* / model_inference / test, driven the
+    way train.py drives the reference's (build -> load_model(dir, epoch) -> test()); class NAMES go through the default
+    tokenizer (OVMR_BPE_PATH), the prompt-learner weights through a Dassl checkpoint directory."""
+    from types import SimpleNamespace
+    from ovmr_amd import checkpoint, modules, trainer
+    from ovmr_amd.tokenizer import BPETokenizer
+    from test_next_rows_cpu import make_synthetic_bpe
+    spec, S, names = synth.SPECS["small"], 4, ["tench", "gold fish", "sea_horse", "yin yang", "hen"]
+    C = len(names)
+    bpe = str(tmp_path / "bpe.txt.gz")
+    make_synthetic_bpe(bpe)
+    monkeypatch.setenv("OVMR_BPE_PATH", bpe)
+    modules._DEFAULT_TOKENIZER.clear()
+    sd_np = synth.clip_state_dict(spec, SEED, jitter=True)
+    pl_np = synth.prompt_learner_state_dict(spec, 2, SEED, True)
+    checkpoint.save_prompt_learner_state({k: torch.from_numpy(v) for k, v in pl_np.items()}, str(tmp_path / "ckpt"), 30)
+    labels = np.repeat(np.array([2, 0, 4, 1, 3]), S)
+    img = torch.from_numpy(synth.images(C * S, spec.image_resolution, 1234, labels, 0.6))
+    tlab = np.arange(7) % C
+    timg = torch.from_numpy(synth.images(7, spec.image_resolution, 777, tlab, 0.6))
+    dm = SimpleNamespace(dataset=SimpleNamespace(classnames=names), val_loader=None,
+                         test_loader=[{"img": timg[:4], "label": torch.from_numpy(tlab[:4])}, {"img": timg[4:], "label": torch.from_numpy(tlab[4:])}],
+                         eval_set_loader=[{"img": img[s:s + 2 * S], "label": torch.from_numpy(labels[s:s + 2 * S])} for s in range(0, C * S, 2 * S)])
+    cfg = modules.make_cfg(n_ctx=2, num_shots=S, output_dir=str(tmp_path / "out"))
+    cfg.TRAINER.NAME = "MM_CLS_OP"
+    with pytest.raises(FileNotFoundError, match="clip_weights"):
+        trainer.build_trainer(cfg, dm)
+    t = trainer.build_trainer(cfg, dm, clip_weights={k: torch.from_numpy(v) for k, v in sd_np.items()})
+    assert isinstance(t, trainer.MM_CLS_OP) and t.get_model_names() == ["prompt_learner"]
+    with pytest.raises(FileNotFoundError, match="Model not found"):
+        t.load_model(str(tmp_path / "ckpt"), epoch=7)
+    t.load_model("")                                                        # "load_model() is skipped"
+    t.load_model(str(tmp_path / "ckpt"), epoch=30)
+    acc = t.test()
+    assert 0.0 <= acc <= 100.0 and (tmp_path / "out" / "mm_classifiers.pt").exists()
+    with pytest.raises(NotImplementedError):
+        t.forward_backward(dm.test_loader[0])
+    # classifier rows against the oracle on the same tokens
+    tok = BPETokenizer(bpe).tokenize(["a " + n.replace("_", " ") + "." for n in names])
+    with torch.no_grad():
+        r = O.forward_prompt(img, torch.from_numpy(labels), tok, _oracle_sd(O, "small"), O.to_torch(pl_np), 2, 10.0, 2, "fp16")
+    saved = torch.load(tmp_path / "out" / "mm_classifiers.pt", map_location="cpu")
+    for k in ("text_classifier", "vision_classifier", "mm_classifier"):
+        assert_cosine(saved[k].numpy(), r[k].numpy(), COS_TOL, k)
+    modules._DEFAULT_TOKENIZER.clear()

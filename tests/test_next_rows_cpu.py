@@ -142,3 +142,68 @@ def test_loader_list_form_k_transforms():
     assert torch.equal(out[0], a[0]) and torch.equal(out[1], b[0]) and torch.equal(out[2], a[1])
     single = CustomCLIP._batch_images({"img": a}, "cpu")
     assert single is a
+
+
+CKPT = os.path.join(REPO, "tests", "golden", "ckpt")
+
+
+def test_reference_written_checkpoint_files():
+    """SURVEY 8f-3 on files the REFERENCE's own writers produced (tests/golden/gen_checkpoints.py): a TorchScript archive
+    of the reference CLIP module (the format of OpenAI's ViT-B-16.pt) and a Dassl save_checkpoint() directory."""
+    from ovmr_amd import checkpoint
+    from ovmr_amd.modules import infer_spec
+    spec = synth.SPECS["micro"]
+    exp = np.load(os.path.join(CKPT, "micro_expected.npz"))
+    sd = checkpoint.load_clip_state_dict(os.path.join(CKPT, "micro_clip_jit.pt"))       # the torch.jit.load branch
+    assert sorted(sd) == sorted(k for k in exp["clip_keys"] if k not in ("input_resolution", "context_length", "vocab_size"))
+    assert {"input_resolution", "context_length", "vocab_size"} <= set(exp["clip_keys"].tolist())
+    got = infer_spec(sd)
+    for f in ("embed_dim", "image_resolution", "vision_layers", "vision_width", "vision_patch_size", "context_length",
+              "vocab_size", "transformer_width", "transformer_heads", "transformer_layers"):
+        assert getattr(got, f) == getattr(spec, f), f
+    ref = synth.clip_state_dict(spec, 11, jitter=True)
+    halved = 0
+    for k, v in ref.items():
+        t = sd[k]
+        if t.dtype == torch.float16:                         # convert_weights() halves conv / linear / attention / projections
+            halved += 1
+            assert torch.equal(t, torch.from_numpy(v).half()), k
+        else:
+            assert t.dtype == torch.float32 and torch.equal(t, torch.from_numpy(v)), k
+    assert halved > 10 and sd["visual.positional_embedding"].dtype == torch.float32 and sd["ln_final.weight"].dtype == torch.float32
+
+    pl_ref = synth.prompt_learner_state_dict(spec, 2, 11, True)
+    raw = torch.load(os.path.join(CKPT, "prompt_learner", "model.pth.tar-30"), map_location="cpu", weights_only=False)
+    assert sorted(raw) == ["epoch", "optimizer", "scheduler", "state_dict", "val_result"] and raw["epoch"] == 30
+    assert "token_prefix" in raw["state_dict"] and "token_suffix" in raw["state_dict"]
+    for epoch in (30, None):                                 # explicit epoch / `checkpoint` pointer file
+        pl = checkpoint.load_prompt_learner_state(CKPT, epoch)
+        assert sorted(pl) == sorted(pl_ref)
+        assert all(torch.equal(pl[k], torch.from_numpy(pl_ref[k])) for k in pl_ref)
+    with pytest.raises(FileNotFoundError, match="Model not found"):
+        checkpoint.load_prompt_learner_state(CKPT, 7)
+
+
+def test_default_tokenizer_from_environment(tmp_path, monkeypatch):
+    """CustomCLIP(cfg, classnames, clip_model) -- the reference's three-argument form -- finds its tokenizer through
+    OVMR_BPE_PATH; without a table the error says what to do."""
+    from ovmr_amd import modules
+    modules._DEFAULT_TOKENIZER.clear()
+    monkeypatch.delenv("OVMR_BPE_PATH", raising=False)
+    monkeypatch.chdir(tmp_path)
+    with pytest.raises(FileNotFoundError, match="OVMR_BPE_PATH"):
+        modules.default_tokenizer()
+    p = str(tmp_path / "bpe.txt.gz")
+    make_synthetic_bpe(p)
+    monkeypatch.setenv("OVMR_BPE_PATH", p)
+    tk = modules.default_tokenizer()
+    assert tk is modules.default_tokenizer()
+    t = modules.tokenize(["a sea horse."], tk)
+    assert t.shape == (1, 77) and int(t[0, 0]) == synth.SOT_ID and int(t.max()) == synth.EOT_ID
+    # ./clip/bpe_simple_vocab_16e6.txt.gz of a reference checkout
+    modules._DEFAULT_TOKENIZER.clear()
+    monkeypatch.delenv("OVMR_BPE_PATH")
+    (tmp_path / "clip").mkdir()
+    os.replace(p, tmp_path / "clip" / "bpe_simple_vocab_16e6.txt.gz")
+    assert modules.default_tokenizer().encode("a") == tk.encode("a")
+    modules._DEFAULT_TOKENIZER.clear()
