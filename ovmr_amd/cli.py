@@ -73,10 +73,21 @@ def read_classnames(root: str, folders: Sequence[str]) -> List[str]:
 
 
 class FolderLoader:
-    """Iterable of {"img", "label"} dict batches (the loader protocol of SURVEY.md 8b)."""
+    """Iterable of {"img", "label"} dict batches (the loader protocol of SURVEY.md 8b).
 
-    def __init__(self, items: Sequence[Tuple[str, int]], batch_size: int, size: int):
-        self.items, self.bs, self.size = list(items), batch_size, size
+    With world > 1 the loader is class-sharded: a rank keeps only the items whose class lies in its contiguous
+    `shard_range` of the `num_classes` classes, so it opens and decodes only its own images; `presharded = True` then tells
+    CustomCLIP.forward_prompt that every batch it receives is its own."""
+
+    def __init__(self, items: Sequence[Tuple[str, int]], batch_size: int, size: int, rank: int = 0, world: int = 1,
+                 num_classes: int = 0):
+        self.bs, self.size = batch_size, size
+        self.presharded = world > 1
+        if world > 1:
+            from .shard import shard_range
+            lo, hi = shard_range(num_classes or (1 + max(l for _, l in items)), rank, world)
+            items = [it for it in items if lo <= it[1] < hi]
+        self.items = list(items)
 
     def __len__(self):
         return (len(self.items) + self.bs - 1) // self.bs
@@ -153,7 +164,9 @@ def main(argv=None) -> Dict[str, float]:
         print("Note that load_model() is skipped as no pretrained model is given")       # :464-466
     model = modules.CustomCLIP(cfg, classnames, clip_model, tokenizer=BPETokenizer(args.bpe_path),
                                prompt_learner_state=pl_state, reserve=(batch, 256, max(1024, len(classnames))))
-    eval_loader = FolderLoader(exemplar_items(eval_all, shots), batch // shots * shots, size)
+    import torch.distributed as dist
+    rank, world = (dist.get_rank(), dist.get_world_size()) if dist.is_available() and dist.is_initialized() else (0, 1)
+    eval_loader = FolderLoader(exemplar_items(eval_all, shots), batch // shots * shots, size, rank, world, len(classnames))
     _, test_items = list_split(args.root, args.test_split)
     evaluator = Classification(len(classnames), classnames, device=args.device)
     for b in FolderLoader(test_items, batch, size):

@@ -356,16 +356,21 @@ class CustomCLIP:
         local = torch.cat(local_labels) if local_labels else torch.zeros(0, dtype=torch.long, device=dev)
 
         if dist:
-            # RCCL all-gather of the packed classifier rows: [mm | v | text | tokens]
-            from .shard import all_gather_rows
+            # ONE all-gather (RCCL) of the packed classifier rows: [mm | v | text | tokens | label bits]
+            from .shard import all_gather_rows, local_class_bound
             packed = torch.cat([self.mm_classifier[local], self.visual_classifer[local], text_clf[local],
                                 self.visual_tokens[local].flatten(1)], dim=1)
-            rows, labels = all_gather_rows(packed, local, dist)
-            self.mm_classifier[labels] = rows[:, :D]
-            self.visual_classifer[labels] = rows[:, D:2 * D]
-            text_clf[labels] = rows[:, 2 * D:3 * D]
-            self.visual_tokens[labels] = rows[:, 3 * D:].reshape(-1, n_ctx, D)
-            self.inference_text_initialized[labels] = 1
+            bound = local_class_bound(C, world, presharded, max(1, self.cfg.DATALOADER.TEST.BATCH_SIZE // S))
+            rows, labels = all_gather_rows(packed, local, bound, dist)
+            full = torch.zeros((C + 1, rows.shape[1]), **f16)                       # row C collects the padding rows
+            full.index_copy_(0, torch.where(labels >= 0, labels, C).long(), rows)
+            seen = torch.zeros(C + 1, dtype=torch.int32, device=dev)
+            seen.index_add_(0, torch.where(labels >= 0, labels, C).long(), torch.ones_like(labels))
+            self.mm_classifier = full[:C, :D].contiguous()
+            self.visual_classifer = full[:C, D:2 * D].contiguous()
+            text_clf = full[:C, 2 * D:3 * D].contiguous()
+            self.visual_tokens = full[:C, 3 * D:].reshape(C, n_ctx, D).contiguous()
+            self.inference_text_initialized = (seen[:C] == 1).to(torch.int32)       # every class from exactly one rank
         if streamed_text:
             self.zero_shot_classifier = self.prompt_learner.zero_shot_classifier = text_clf
         assert bool(self.inference_text_initialized.bool().all()), "a class received no exemplar batch"   # :259
@@ -395,7 +400,8 @@ class CustomCLIP:
             for m, clf in enumerate((mm_classifier, v_classifier, t_classifier)):   # order :272
                 e.xval_counts(rows, row_labels, clf, counts[m, 0], counts[m, 1])
         if dist:
-            dist.all_reduce(counts)
+            from .shard import all_reduce_counts
+            counts = all_reduce_counts(counts, dist)                                # ONE all-reduce
         n_label = torch.full((C,), S, dtype=torch.int32, device=dev)
         self.xval_counts = counts
         return e.fusion_weights(counts, n_label, tau)

@@ -5,8 +5,10 @@ The reference has no distributed path; the path shards naturally
 independent until the cross-validation step:
   * every rank encodes the exemplars of its own classes and produces their mm / vision / text
     classifier rows and visual tokens;
-  * ONE all-gather of the packed rows [n_local, 3*D + n_ctx*D] fp16 assembles the classifier matrix
-    (3 MB in total at 1000 classes: latency bound, far below the ~153 GB/s of one xGMI link);
+  * ONE all-gather of the packed rows [bound, 3*D + n_ctx*D + 2] fp16 (mm | vision | text | visual tokens | label bits)
+    assembles the classifier matrix (5 MB in total at 1000 classes: latency bound, far below the ~153 GB/s of one xGMI
+    link); the per-rank block size `bound` follows from C, the world size and the loader contract, so no size exchange
+    precedes it;
   * every rank runs the argmax counting for its own exemplar rows against all classes and ONE
     all-reduce sums the int32 [3,2,C] counters (n_pred[c] receives votes from other ranks' rows).
 """
@@ -29,22 +31,46 @@ def shard_batches(num_batches: int, rank: int, world: int) -> List[int]:
     return [i for i in range(num_batches) if i % world == rank]
 
 
-def all_gather_rows(rows: torch.Tensor, labels: torch.Tensor, dist) -> Tuple[torch.Tensor, torch.Tensor]:
-    """All-gather a ragged set of rows.  rows [n_local, K], labels [n_local] int64 (class ids).
-    Returns (all_rows [n_total, K], all_labels [n_total]) in rank order."""
+def local_class_bound(num_classes: int, world: int, presharded: bool, classes_per_batch: int) -> int:
+    """Upper bound of the classes ONE rank produces, computed from values every rank knows (no communication).
+    presharded loaders own a contiguous `shard_range` of the classes; otherwise batch i belongs to rank i % world and a
+    batch holds at most `classes_per_batch` = TEST.BATCH_SIZE // NUM_SHOTS classes (SURVEY.md 8a-0), which bounds a rank's
+    share by C / world + 2 * classes_per_batch for any batch size up to that."""
+    if presharded:
+        return -(-num_classes // world)
+    return -(-num_classes // world) + 2 * max(1, classes_per_batch)
+
+
+def _staged(t: torch.Tensor, dist) -> torch.Tensor:
+    """gloo moves host memory: stage device tensors through the CPU (CPU tests, or several ranks sharing one GPU)."""
+    return t.cpu() if dist.get_backend() == "gloo" and t.is_cuda else t
+
+
+def all_gather_rows(rows: torch.Tensor, labels: torch.Tensor, bound: int, dist) -> Tuple[torch.Tensor, torch.Tensor]:
+    """ONE all-gather of a ragged set of fp16 rows.  rows [n_local, K] fp16, labels [n_local] (class ids), n_local <= bound
+    (`local_class_bound`, identical on every rank).  Every rank contributes a [bound, K + 2] block: its rows, the int32
+    label of each row carried in two extra fp16 columns (bit pattern, not value), padding rows labelled -1.
+    Returns (all_rows [world * bound, K], all_labels [world * bound] int32 with -1 on padding rows), rank-major."""
+    n, K = rows.shape
+    if n > bound:
+        raise RuntimeError(f"this rank produced {n} classes, more than the bound {bound} every rank agreed on: the eval-set "
+                           "loader yields more than TEST.BATCH_SIZE // NUM_SHOTS classes per batch")
+    assert rows.dtype == torch.float16
     world = dist.get_world_size()
-    n = torch.tensor([rows.shape[0]], dtype=torch.int64, device=rows.device)
-    counts = [torch.zeros_like(n) for _ in range(world)]
-    dist.all_gather(counts, n)
-    nmax = max(int(c.item()) for c in counts)
-    pad_rows = torch.zeros((nmax, rows.shape[1]), dtype=rows.dtype, device=rows.device)
-    pad_labels = torch.full((nmax,), -1, dtype=torch.int64, device=rows.device)
-    pad_rows[:rows.shape[0]] = rows
-    pad_labels[:rows.shape[0]] = labels.to(torch.int64)
-    out_rows = [torch.empty_like(pad_rows) for _ in range(world)]
-    out_labels = [torch.empty_like(pad_labels) for _ in range(world)]
-    dist.all_gather(out_rows, pad_rows)
-    dist.all_gather(out_labels, pad_labels)
-    all_rows, all_labels = torch.cat(out_rows), torch.cat(out_labels)
-    keep = all_labels >= 0
-    return all_rows[keep], all_labels[keep]
+    lab = torch.full((bound,), -1, dtype=torch.int32, device=rows.device)
+    lab[:n] = labels.to(torch.int32)
+    block = torch.zeros((bound, K + 2), dtype=torch.float16, device=rows.device)
+    block[:n, :K] = rows
+    block[:, K:] = lab.view(torch.float16).reshape(bound, 2)
+    block = _staged(block, dist)
+    out = torch.empty((world * bound, K + 2), dtype=torch.float16, device=block.device)
+    dist.all_gather_into_tensor(out, block)
+    out = out.to(rows.device)
+    return out[:, :K], out[:, K:].contiguous().view(torch.int32).reshape(-1)
+
+
+def all_reduce_counts(counts: torch.Tensor, dist) -> torch.Tensor:
+    """ONE all-reduce (sum) of the int32 [3, 2, C] argmax counters."""
+    c = _staged(counts, dist)
+    dist.all_reduce(c)
+    return c.to(counts.device)

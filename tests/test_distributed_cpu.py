@@ -16,7 +16,7 @@ import torch.multiprocessing as mp
 from conftest import REPO
 from ovmr_amd import synth
 
-SEED, N_CTX, S, C = 11, 2, 4, 6
+SEED, N_CTX, S = 11, 2, 4
 
 
 class OracleEngine:
@@ -95,7 +95,7 @@ class FakeCLIPModel:
         return self._e[n_ctx]
 
 
-def _run(rank, world, port, outdir, result):
+def _run(rank, world, port, outdir, result, C=6, presharded=False):
     sys.path.insert(0, REPO)
     torch.set_num_threads(2)
     if world > 1:
@@ -107,9 +107,16 @@ def _run(rank, world, port, outdir, result):
     pl = {k: torch.from_numpy(v) for k, v in synth.prompt_learner_state_dict(spec, N_CTX, SEED, True).items()}
     tok = torch.from_numpy(synth.class_token_ids(C, seed=4321))
     model = modules.CustomCLIP(cfg, tok, FakeCLIPModel(spec), prompt_learner_state=pl, reserve=(8, 8, 8))
-    labels = np.repeat(np.array([3, 0, 5, 1, 2, 4]), S)
+    labels = np.repeat(np.random.default_rng(2).permutation(C), S)
     img = torch.from_numpy(synth.images(C * S, spec.image_resolution, 1234, labels, 0.6))
-    loader = [{"img": img[s:s + S], "label": torch.from_numpy(labels[s:s + S])} for s in range(0, C * S, S)]  # 6 batches
+    if presharded:                                                  # class-sharded loader: only this rank's classes exist here
+        from ovmr_amd.data import ResidentEvalSet
+        from ovmr_amd.shard import shard_range
+        a, b = shard_range(C, rank, world)
+        mine = np.concatenate([np.nonzero(labels == c)[0] for c in range(a, b)]) if b > a else np.zeros(0, dtype=np.int64)
+        loader = ResidentEvalSet(img[mine], torch.arange(a, b), S, 2, presharded=world > 1)
+    else:                                                           # one class per batch, batch i -> rank i % world
+        loader = [{"img": img[s:s + S], "label": torch.from_numpy(labels[s:s + S])} for s in range(0, C * S, S)]
     q = torch.from_numpy(synth.images(5, spec.image_resolution, 777))
     out = model(q, eval_set_loader=loader)
     w_gen = model.fusion_weight.clone()
@@ -135,12 +142,14 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.timeout(600)
-def test_two_rank_generation_matches_single_process():
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("world,C,presharded", [(2, 6, False), (4, 7, False), (4, 7, True)])
+def test_multi_rank_generation_matches_single_process(world, C, presharded):
+    """2 ranks x 6 classes; 4 ranks x 7 classes (ragged: shards of 2, 2, 2, 1), round-robin batches and class-sharded loader."""
     with tempfile.TemporaryDirectory() as d:
         r1, r2 = os.path.join(d, "single.pt"), os.path.join(d, "dist.pt")
-        _run(0, 1, 0, os.path.join(d, "o1"), r1)
-        mp.spawn(_run, args=(2, _free_port(), os.path.join(d, "o2"), r2), nprocs=2, join=True)
+        _run(0, 1, 0, os.path.join(d, "o1"), r1, C, False)
+        mp.spawn(_run, args=(world, _free_port(), os.path.join(d, "o2"), r2, C, presharded), nprocs=world, join=True)
         a, b = torch.load(r1), torch.load(r2)
         for k in ("mm", "v", "t", "tokens"):
             assert torch.equal(a[k], b[k]), k                      # rows are computed independently per class
@@ -155,13 +164,24 @@ def _gather(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     sys.path.insert(0, REPO)
-    from ovmr_amd.shard import all_gather_rows, shard_range
+    from ovmr_amd.shard import all_gather_rows, all_reduce_counts, local_class_bound, shard_range
+    C = 70001                                                       # labels beyond fp16's exact-integer range
     full = torch.arange(7 * 3, dtype=torch.float16).reshape(7, 3)
-    a, b = shard_range(7, rank, world)                              # ragged: 4 + 3 rows
-    rows, labels = all_gather_rows(full[a:b], torch.arange(a, b), dist)
-    out = torch.zeros_like(full)
-    out[labels] = rows
-    ok = torch.equal(out, full) and sorted(labels.tolist()) == list(range(7))
+    ids = torch.tensor([0, 5, 2047, 2049, 40000, 65537, 70000])
+    a, b = shard_range(7, rank, world)                              # ragged: world 4 -> 2 + 2 + 2 + 1 rows
+    bound = local_class_bound(7, world, True, 1)
+    rows, labels = all_gather_rows(full[a:b], ids[a:b], bound, dist)
+    ok = rows.shape == (world * bound, 3) and labels.dtype == torch.int32
+    keep = labels >= 0
+    ok = ok and int(keep.sum()) == 7 and torch.equal(labels[keep].long(), ids) and torch.equal(rows[keep], full)
+    ok = ok and bool((rows[~keep] == 0).all())
+    counts = torch.full((3, 2, 5), rank + 1, dtype=torch.int32)
+    ok = ok and torch.equal(all_reduce_counts(counts, dist), torch.full((3, 2, 5), world * (world + 1) // 2, dtype=torch.int32))
+    try:
+        all_gather_rows(full, torch.arange(7), 3, dist)
+        ok = False
+    except RuntimeError as e:
+        ok = ok and "more than the bound" in str(e)
     if rank == 0:
         q.put(ok)
     dist.barrier()
@@ -169,8 +189,23 @@ def _gather(rank, world, port, q):
 
 
 @pytest.mark.timeout(300)
-def test_ragged_all_gather_rows():
+@pytest.mark.parametrize("world", [2, 4])
+def test_ragged_all_gather_rows(world):
     ctx = mp.get_context("spawn")
     q = ctx.SimpleQueue()
-    mp.spawn(_gather, args=(2, _free_port(), q), nprocs=2, join=True)
+    mp.spawn(_gather, args=(world, _free_port(), q), nprocs=world, join=True)
     assert q.get() is True
+
+
+def test_local_class_bound_covers_round_robin_batches():
+    """The bound every rank computes without communication is never below what a rank can receive."""
+    from ovmr_amd.shard import local_class_bound, shard_batches, shard_range
+    for C in (1, 6, 7, 100, 1000, 1003):
+        for world in (1, 2, 3, 4, 8):
+            assert local_class_bound(C, world, True, 16) == max(shard_range(C, r, world)[1] - shard_range(C, r, world)[0] for r in range(world))
+            for cfg_cpb in (1, 4, 16):
+                for cpb in range(1, cfg_cpb + 1):                   # loaders may yield smaller batches than TEST.BATCH_SIZE // S
+                    nb = -(-C // cpb)
+                    sizes = [min(cpb, C - i * cpb) for i in range(nb)]
+                    worst = max(sum(sizes[i] for i in shard_batches(nb, r, world)) for r in range(world))
+                    assert worst <= local_class_bound(C, world, False, cfg_cpb), (C, world, cfg_cpb, cpb)

@@ -1,0 +1,45 @@
+"""N > 1 on the real engine (`pytest -m gpu`): classifier generation as 2 and 3 processes sharing the test box's one GPU
+(process group gloo; on a multi-GPU node the same orchestration runs over RCCL) must reproduce the single-process HIP result
+BIT FOR BIT -- classifier rows are computed independently per class, the argmax counters are integer sums."""
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+WORKER = os.path.join(os.path.dirname(os.path.abspath(__file__)), "dist_gpu_worker.py")
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _launch(world, result, presharded, C):
+    port = _free_port()
+    procs = []
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, WORKER, result, str(presharded), str(C)], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o[-3000:]
+    return torch.load(result)
+
+
+@pytest.mark.timeout(1500)
+def test_multi_process_generation_bit_equal_to_single_process(tmp_path):
+    C = 7                                                             # ragged over 2 and 3 ranks
+    single = _launch(1, str(tmp_path / "w1.pt"), 0, C)
+    assert single["files"] == ["mm_classifiers.pt", "visual_tokens.pt"]
+    for world, presharded in ((2, 0), (2, 1), (3, 1)):
+        got = _launch(world, str(tmp_path / f"w{world}_{presharded}.pt"), presharded, C)
+        for k in ("mm", "v", "t", "tokens", "counts", "w", "out"):
+            assert torch.equal(single[k], got[k]), f"world {world} presharded {presharded}: {k} differs"
+        assert got["files"] == ["mm_classifiers.pt", "visual_tokens.pt"]          # rank 0 wrote the files
