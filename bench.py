@@ -6,18 +6,20 @@ One STEP = one whole classifier-generation job plus fusion-mode inference, nothi
   generation  16 000 exemplar images (1000 classes x 16 shots) -> image encoder -> visual-token
               generator -> multimodal / vision prompts -> text encoder (mm, vision, zero-shot text
               classifiers) -> cross-validation argmax counts -> F1 -> fusion weights;
-  inference   --queries images in batches of 256 -> image encoder -> three classifier GEMMs ->
-              softmax -> fused probabilities.
+  inference   --queries images in batches of --query-batch (256 = BASELINE config 3) -> image encoder -> three
+              classifier GEMMs -> softmax -> fused probabilities.
 value = (exemplar + query images of ALL ranks) / wall time of a step, inputs resident in HBM.
 With N > 1 (launched by torch.distributed.run, one process per GPU, backend nccl = RCCL) the classes
 and the queries are sharded over ranks (strong scaling of the named 1k-class job); the only data-path
 collectives are one all-gather of classifier rows and one all-reduce of the F1 counters.
 
 The JSON line also carries
-  roofline      the dominant kernel (fp16 MFMA GEMM, c_fc shape 50432x3072x768) timed live with HIP events
+  roofline      the dominant kernel (fp16 MFMA GEMM at the c_fc launch shape of the job: M = batch x 197 = 100864 token
+                rows at batch 512, N = 3072, K = 768, ln_2 fold + bias + QuickGELU epilogue) timed live with HIP events
                 on the stream it is launched on, against the 2.5 PFLOP/s dense fp16 MFMA peak;
   cpu_baseline  the CPU oracle (a torch-CPU port of the reference path, validated against golden vectors of
-                the real reference) timed on this host's cores on a bounded sample (rank 0, N = 1 only).
+                the real reference) timed on ALL of this host's cores (cores // 16 worker processes x 16 threads on disjoint
+                class slices, 1 warm-up + 3 timed repetitions, median) on a bounded sample (rank 0, N = 1 only).
 """
 import argparse
 import json
@@ -39,14 +41,17 @@ def parse():
     ap.add_argument("--classes", type=int, default=1000)
     ap.add_argument("--shots", type=int, default=16)
     ap.add_argument("--queries", type=int, default=4096)
-    ap.add_argument("--batch", type=int, default=512, help="images per encoder launch sequence")
+    ap.add_argument("--batch", type=int, default=512, help="exemplar images per encoder launch sequence")
+    ap.add_argument("--query-batch", type=int, default=256, help="query images per inference call (256 = BASELINE config 3)")
     ap.add_argument("--classes-per-batch", type=int, default=256)
     ap.add_argument("--gemm", type=int, default=int(os.environ.get("OVMR_GEMM", "6")))
     ap.add_argument("--attn", type=int, default=int(os.environ.get("OVMR_ATTN", "1")))
     ap.add_argument("--ln-fold", type=int, default=int(os.environ.get("OVMR_LN_FOLD", "1")),
                     help="1: ln_1/ln_2 folded into the consuming GEMM epilogue; 0: separate LayerNorm kernels")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-classes", type=int, default=16)
+    ap.add_argument("--cpu-sample-classes", type=int, default=2, help="classes per CPU worker process and repetition (0: skip)")
+    ap.add_argument("--cpu-threads", type=int, default=16, help="threads per CPU worker process")
+    ap.add_argument("--cpu-reps", type=int, default=3)
     return ap.parse_args()
 
 
@@ -115,8 +120,8 @@ def main():
                 model.prompt_learner.encode_zero_shot(model.tokenized_prompts)     # part of the job (:118-126)
         model.forward_prompt(loader)
         outs = None
-        for b in range(0, q_img.shape[0], args.batch):
-            outs = model(q_img[b:b + args.batch])
+        for b in range(0, q_img.shape[0], args.query_batch):
+            outs = model(q_img[b:b + args.query_batch])
         return outs
 
     def barrier():
@@ -145,8 +150,8 @@ def main():
     barrier()
     tg = time.perf_counter(); model.forward_prompt(loader); torch.cuda.synchronize(); tg = time.perf_counter() - tg
     ti = time.perf_counter()
-    for b in range(0, q_img.shape[0], args.batch):
-        model(q_img[b:b + args.batch])
+    for b in range(0, q_img.shape[0], args.query_batch):
+        model(q_img[b:b + args.query_batch])
     torch.cuda.synchronize(); ti = time.perf_counter() - ti
 
     images_per_step = C * S + Q
@@ -164,7 +169,7 @@ def main():
             "ms_per_step": round(1000 * dt / args.steps, 3), "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f16", "data": "synthetic",
             "config": {"workload": f"OVMR classifier generation + fusion inference, {args.model}, {C} classes x {S} shots "
-                                   f"({C * S} exemplar images) + {Q} query images, batch {args.batch}, n_ctx 2, tau 10",
+                                   f"({C * S} exemplar images, batch {args.batch}) + {Q} query images (batch {args.query_batch}), n_ctx 2, tau 10",
                        "parallelism": f"class/query sharding over {world} rank(s); all-gather rows + all-reduce counters",
                        "gemm_variant": args.gemm, "attn_variant": args.attn, "ln_fold": args.ln_fold,
                        "images_per_step": images_per_step},
@@ -172,6 +177,7 @@ def main():
             "cpu_baseline": cpu,
             "phases": {"generation_images_per_s_rank0": round((c1 - c0) * S / tg, 1),
                        "inference_images_per_s_rank0": round((q1 - q0) / ti, 1) if q1 > q0 else None,
+                       "inference_query_batch": args.query_batch,
                        "encoder_tflops_e2e": round(value * flops_img / 1e12, 1),
                        "e2e_frac_of_fp16_mfma_peak": round(value * flops_img / 1e12 / (2500.0 * world), 4)},
         }
@@ -311,54 +317,88 @@ def pmc_traffic(variant, M, N, batch, epi=2):
     return {"traffic": None}
 
 
-def cpu_baseline(spec, sd, pl, tok, args, n_ctx):
-    """The oracle (torch-CPU port of the reference path) on a bounded sample of the same workload.
-    1. thread count: the fp32 encoder on 2 images at {all cores, 64, 32, 16} threads, best kept (a 256-thread
-       pool is slower than 32 threads on this path);
-    2. generation + fusion: `--cpu-sample-classes` classes x shots through forward_prompt + 4 fused queries in the
-       oracle's fp32 mode (fp16-rounded weights, fp32 math: what the reference computes after clip_model.float());
-    3. the fp16 mode (the only precision the reference's OVMR path runs as shipped) on 2 images, encoder only.
-    The faster images/s is the reported value."""
+def _cpu_worker(widx, nproc, threads, spec_name, sd16, pl, tok, shots, classes, reps, n_ctx, barrier, queue):
+    """One CPU worker: `classes` classes x `shots` exemplars of its own slice through the oracle's forward_prompt + fused
+    inference on 4 queries, 1 warm-up + `reps` timed repetitions in fp32 (what the reference computes after clip_model.float())
+    and the same in fp16 (the precision its OVMR path runs in as shipped).  All workers start each repetition together."""
     import torch
     from oracle import ovmr_oracle as O
-    cores = os.cpu_count()
-    S, Cs, R = args.shots, args.cpu_sample_classes, spec.image_resolution
-    cpu_sd = O.convert_weights({k: v.detach().float().cpu() for k, v in sd.items()}, "fp16")
-    sd32 = {k: v.float() for k, v in cpu_sd.items()}
-    cpu_pl = {k: v.detach().float().cpu() for k, v in pl.items()}
-    g = torch.Generator().manual_seed(3)
-    img = torch.randn((Cs * S, 3, R, R), generator=g)
+    from ovmr_amd import synth
+    torch.set_num_threads(threads)
+    spec = synth.SPECS[spec_name]
+    R = spec.image_resolution
+    sd32 = {k: v.float() for k, v in sd16.items()}
+    g = torch.Generator().manual_seed(3 + widx)
+    img = torch.randn((classes * shots, 3, R, R), generator=g)
     q = torch.randn((4, 3, R, R), generator=g)
-    labels = torch.arange(Cs).repeat_interleave(S)
-    probe = {}
+    labels = torch.arange(classes).repeat_interleave(shots)
+    mytok = tok[widx * classes:(widx + 1) * classes]
+
+    def job(sd, prec, x, qx):
+        r = O.forward_prompt(x, labels, mytok, sd, pl, n_ctx, 10.0, max(1, 64 // shots), prec)
+        qf = O.l2_normalize(O.encode_image(qx, sd))
+        O.inference_logits(qf, r["mm_classifier"].to(qf.dtype), r["vision_classifier"].to(qf.dtype), r["text_classifier"].to(qf.dtype),
+                           r["fusion_weight"], sd["logit_scale"].float().exp(), "fusion")
+
+    times32, times16 = [], []
     with torch.no_grad():
-        for nt in sorted({cores, 64, 32, 16}, reverse=True):
-            if nt > cores:
-                continue
-            torch.set_num_threads(nt)
-            O.encode_image(img[:1], sd32)
-            t0 = time.perf_counter()
-            O.encode_image(img[:2], sd32)
-            probe[nt] = 2 / (time.perf_counter() - t0)
-        threads = max(probe, key=probe.get)
-        torch.set_num_threads(threads)
-        t0 = time.perf_counter()
-        r = O.forward_prompt(img, labels, tok[:Cs], sd32, cpu_pl, n_ctx, 10.0, max(1, 256 // S), "fp32")
-        qf = O.l2_normalize(O.encode_image(q, sd32))
-        O.inference_logits(qf, r["mm_classifier"], r["vision_classifier"], r["text_classifier"],
-                           r["fusion_weight"], sd32["logit_scale"].exp(), "fusion")
-        t32 = time.perf_counter() - t0
-        t0 = time.perf_counter()
-        O.encode_image(img[:2].half(), cpu_sd)
-        t16 = time.perf_counter() - t0
-    v32 = (Cs * S + 4) / t32
-    v16 = 2 / t16
-    return {"value": round(max(v16, v32), 3), "unit": "images/s", "cores": threads, "kind": "port",
-            "sample": f"{Cs} class(es) x {S} shots generation + 4 fusion queries, fp32 math on fp16-rounded weights "
-                      f"({t32:.1f} s, {v32:.2f} img/s) with {threads} of {cores} host threads; fp16 encoder-only on 2 images "
-                      f"{v16:.2f} img/s; faster of the two reported",
-            "host_cores": cores, "thread_probe_images_per_s": {str(k): round(v, 2) for k, v in probe.items()},
-            "fp16_encode_images_per_s": round(v16, 3), "fp32_generation_images_per_s": round(v32, 3)}
+        for sdx, prec, x, qx, out in ((sd32, "fp32", img, q, times32), (sd16, "fp16", img.half(), q.half(), times16)):
+            for rep in range(reps + 1):                              # rep 0 = warm-up
+                barrier.wait()
+                t0 = time.perf_counter()
+                job(sdx, prec, x, qx)
+                if rep:
+                    out.append(time.perf_counter() - t0)
+    queue.put((widx, times32, times16))
+
+
+def cpu_baseline(spec, sd, pl, tok, args, n_ctx):
+    """The oracle (torch-CPU port of the reference path) on the WHOLE host: cores // threads worker processes x `--cpu-threads`
+    threads (a single 256-thread pool is far slower than 16-thread pools on this path), disjoint class slices of
+    `--cpu-sample-classes` classes x shots (batch 32 at the defaults), 1 warm-up + `--cpu-reps` timed repetitions, median.
+    Whole-host images/s = sum over workers of images per repetition / median repetition time, all workers running together.
+    Reported: the faster of fp32-math-on-fp16-rounded-weights and fp16."""
+    import statistics
+    import torch
+    import torch.multiprocessing as mp
+    from oracle import ovmr_oracle as O
+    cores = os.cpu_count()
+    threads = max(1, min(args.cpu_threads, cores))
+    nproc = max(1, cores // threads)
+    S, Cs = args.shots, args.cpu_sample_classes
+    sd16 = O.convert_weights({k: v.detach().float().cpu() for k, v in sd.items()}, "fp16")
+    for v in sd16.values():
+        v.share_memory_()
+    cpu_pl = {k: v.detach().float().cpu().share_memory_() for k, v in pl.items()}
+    ctx = mp.get_context("spawn")                                  # this process has initialised the GPU: no fork
+    barrier, queue = ctx.Barrier(nproc), ctx.SimpleQueue()
+    t_all = time.perf_counter()
+    procs = [ctx.Process(target=_cpu_worker, args=(i, nproc, threads, spec.name, sd16, cpu_pl, tok[:nproc * Cs].clone(), S, Cs,
+                                                   args.cpu_reps, n_ctx, barrier, queue)) for i in range(nproc)]
+    for p in procs:
+        p.start()
+    res = [queue.get() for _ in procs]
+    for p in procs:
+        p.join()
+    t_all = time.perf_counter() - t_all
+    n_img = Cs * S + 4
+    per32 = [n_img / statistics.median(t) for _, t, _ in res]
+    per16 = [n_img / statistics.median(t) for _, _, t in res]
+    v32, v16 = sum(per32), sum(per16)
+    model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            model = next(l.split(":", 1)[1].strip() for l in f if l.startswith("model name"))
+    except Exception:
+        pass
+    return {"value": round(max(v16, v32), 2), "unit": "images/s", "cores": nproc * threads, "kind": "port",
+            "sample": f"{nproc} worker processes x {threads} threads, each {Cs} class(es) x {S} shots generation + 4 fusion queries "
+                      f"(batch {Cs * S}) on its own class slice, 1 warm-up + {args.cpu_reps} timed repetitions, median; whole host "
+                      f"fp32 math on fp16-rounded weights {v32:.1f} img/s, fp16 {v16:.1f} img/s, faster reported; "
+                      f"{t_all:.0f} s wall incl. process start",
+            "host_cores": cores, "cpu_model": model, "processes": nproc, "threads_per_process": threads,
+            "per_process_images_per_s": round(statistics.median(per32 if v32 >= v16 else per16), 3),
+            "fp16_images_per_s": round(v16, 2), "fp32_images_per_s": round(v32, 2)}
 
 
 if __name__ == "__main__":
