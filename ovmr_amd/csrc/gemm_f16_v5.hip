@@ -133,10 +133,12 @@ __global__ __launch_bounds__(512) void gemm_f16_v5_kernel(GemmArgs a, int tiles_
     const int b_row_off = A_BYTES + (wn * 64 + fr) * 128;
     const int ch0 = ((fg) ^ (fr & 7)) << 4, ch1 = ((4 + fg) ^ (fr & 7)) << 4;
 
-    stage(0, 0);
+    constexpr bool PH8 = (OPT & 16) != 0 && MT == 8;
+    if (!PH8) stage(0, 0);
 
     // epilogue constants -> LDS, under the latency of the first K-tile (first read after the K loop: many barriers later)
-    if (tid < BN5) {
+    if (PH8) {
+    } else if (tid < BN5) {
         const int n = n0 + tid;
         float c0 = 0.f, c1 = 0.f;
         if (n < a.N) {
@@ -157,6 +159,189 @@ __global__ __launch_bounds__(512) void gemm_f16_v5_kernel(GemmArgs a, int tiles_
         row_c[BM + r] = -rstd * mean;
     }
 
+    if constexpr ((OPT & 16) != 0 && MT == 8) {
+    // ------------------------------------------------------------------------------------------------------------------
+    // 8-phase ping-pong K loop (OPT & 16; the 256x256 tile only).  Structure of the CDNA4 guide's "256^2 8-phase template":
+    //   * a K-tile is staged as FOUR 16 KiB half-tiles -- B0, A0, B1, A1 -- into 2 x 4 LDS slots (128 KiB as before);
+    //     A half h holds the tile rows wm*128 + h*64 + [0,64) of BOTH wave rows, B half g the tile columns
+    //     wn*64 + g*32 + [0,32) of all four wave columns, so in phase (h, g) EVERY wave works on the same two half-tiles
+    //     while its own 128 x 64 output block stays contiguous (the epilogue below is unchanged);
+    //   * four phases per K-tile, one 64 x 32 quadrant of the wave's block (16 MFMAs) each: (A0,B0) (A0,B1) (A1,B1) (A1,B0);
+    //     fragment reads: 12 / 4 / 8 / 0 per phase, every phase also issues ONE half-tile of LDS-DMA (2 instructions);
+    //   * the half-tiles of the next tiles are issued 3..4 phases ahead of their first read and the wait is COUNTED
+    //     (vmcnt(6) once per K-tile, never 0 inside the loop): three half-tiles stay in flight across the barriers;
+    //   * the two wave rows run ONE barrier apart: while wm = 0 issues its MFMAs, wm = 1 reads fragments and issues DMA,
+    //     then they swap -- each SIMD holds one wave of either row, so its matrix pipe and its LDS / VMEM issue alternate.
+    // Slot reuse (WAR) follows the guide's rule: a half-tile is restaged >= 2 phases after its last fragment read (B0: one
+    // phase after, its reads are retired by the lgkmcnt(8) in front of the reading phase's first barrier); a staged
+    // half-tile is first read one phase after the counted wait + barrier that retires it (RAW).
+    // ------------------------------------------------------------------------------------------------------------------
+    constexpr int SLOT = 16384, KBUF = 4 * SLOT;
+    enum { hB0 = 0, hA0 = 1, hB1 = 2, hA1 = 3 };
+    unsigned sa8[2][2], sb8[2][2];                      // [half][8-row piece]: byte offset of this lane's source row
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int lr = wave * 16 + j * 8 + srow;                                    // local row inside the half-tile
+            const int ra = m0 + (lr >> 6) * 128 + hf * 64 + (lr & 63);
+            const int rb = n0 + (lr >> 5) * 64 + hf * 32 + (lr & 31);
+            sa8[hf][j] = src_off(a.a_blocked ? ra : min(ra, a.M - 1), a.lda, a.a_blocked);
+            sb8[hf][j] = src_off(a.w_blocked ? rb : min(rb, a.N - 1), a.ldw, a.w_blocked);
+        }
+    auto stage_half = [&](int buf, int which, int kt) {
+        char* base = smem + buf * KBUF + which * SLOT + wave * 2048;
+        const int hf = which >> 1;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            if (which & 1)
+                __builtin_amdgcn_global_load_lds((gptr_t)((const char*)A + sa8[hf][j] + (long)kt * a_step), (lptr_t)(base + j * 1024), 16, 0, (OPT & 1) ? 2 : 0);
+            else
+                __builtin_amdgcn_global_load_lds((gptr_t)((const char*)W + sb8[hf][j] + (long)kt * w_step), (lptr_t)(base + j * 1024), 16, 0, (OPT & 2) ? 2 : 0);
+        }
+    };
+    const int a_lane = (wm * 64 + fr) * 128, b_lane = (wn * 32 + fr) * 128;
+    half8_t fa[4][2], fb0[2][2], fb1[2][2];
+    auto read_a = [&](const char* buf, int hf) {
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii) {
+            fa[ii][0] = *(const half8_t*)(buf + (1 + 2 * hf) * SLOT + a_lane + ii * 2048 + ch0);
+            fa[ii][1] = *(const half8_t*)(buf + (1 + 2 * hf) * SLOT + a_lane + ii * 2048 + ch1);
+        }
+    };
+    auto read_b = [&](const char* buf, int g, half8_t (&fb)[2][2]) {
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            fb[jj][0] = *(const half8_t*)(buf + 2 * g * SLOT + b_lane + jj * 2048 + ch0);
+            fb[jj][1] = *(const half8_t*)(buf + 2 * g * SLOT + b_lane + jj * 2048 + ch1);
+        }
+    };
+    auto quadrant = [&](int hf, int g, half8_t (&fb)[2][2]) {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int st = 0; st < 2; ++st)
+#pragma unroll
+            for (int ii = 0; ii < 4; ++ii)
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj)
+                    acc[hf * 4 + ii][g * 2 + jj] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[jj][st], fa[ii][st], acc[hf * 4 + ii][g * 2 + jj], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+    };
+#define OVMR_PH_MID(LGKM)                                                 \
+    __builtin_amdgcn_sched_barrier(0);                                    \
+    LGKM;                                                                 \
+    __builtin_amdgcn_s_barrier();                                         \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                    \
+    __builtin_amdgcn_sched_barrier(0);
+#define OVMR_PH_END()                                                     \
+    __builtin_amdgcn_sched_barrier(0);                                    \
+    __builtin_amdgcn_s_barrier();                                         \
+    __builtin_amdgcn_sched_barrier(0);
+
+    // prologue: tile 0 complete, three half-tiles of tile 1 in flight
+    stage_half(0, hB0, 0); stage_half(0, hA0, 0); stage_half(0, hB1, 0); stage_half(0, hA1, 0);
+    // epilogue constants -> LDS (the compiler waits for their global loads with vmcnt(0), i.e. also for tile 0, which the first
+    // phase needs anyway; first read after the K loop)
+    if (tid < BN5) {
+        const int n = n0 + tid;
+        float c0 = 0.f, c1 = 0.f;
+        if (n < a.N) {
+            if (HAS_BIAS) c0 = (float)((const half_t*)a.bias)[n];
+            if (LNF) { c0 = a.ln_g[n]; c1 = a.ln_b[n]; }
+        }
+        col_c[tid] = c0;
+        col_c[BN5 + tid] = c1;
+    } else if (LNF && tid - BN5 < BM) {
+        const int r = tid - BN5;
+        const float2_t* sp = (const float2_t*)a.ln_stats + (long)min(m0 + r, a.M - 1) * a.ln_slots;
+        float su = 0.f, sq = 0.f;
+        for (int sl = 0; sl < a.ln_slots; ++sl) { const float2_t p = sp[sl]; su += p[0]; sq += p[1]; }
+        const float inv_k = 1.0f / (float)a.K;
+        const float mean = su * inv_k;
+        const float rstd = 1.0f / sqrtf(fmaxf(sq * inv_k - mean * mean, 0.f) + 1e-5f);
+        row_c[r] = rstd;
+        row_c[BM + r] = -rstd * mean;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    stage_half(1, hB0, 1); stage_half(1, hA0, 1); stage_half(1, hB1, 1);
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    if (wm == 1) __builtin_amdgcn_s_barrier();          // the second wave row runs one barrier behind the first
+    __builtin_amdgcn_sched_barrier(0);
+    const char* const bufE = smem;
+    const char* const bufO = smem + KBUF;
+    for (int kt = 0; kt < nk; kt += 2) {
+        const bool more = kt + 2 < nk;                  // tiles kt+2 / kt+3 exist (nk is even)
+        // ---- phase 1: (A0, B0) of the even tile; stage A1 of the odd tile kt+1
+        read_b(bufE, 0, fb0);
+        __builtin_amdgcn_sched_barrier(0);
+        read_a(bufE, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        stage_half(1, hA1, kt + 1);
+        OVMR_PH_MID(asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory"))
+        quadrant(0, 0, fb0);
+        OVMR_PH_END()
+        // ---- phase 2: (A0, B1); stage B0 of tile kt+2 (its slot was last read in phase 1)
+        read_b(bufE, 1, fb1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) stage_half(0, hB0, kt + 2);
+        OVMR_PH_MID((void)0)
+        quadrant(0, 1, fb1);
+        OVMR_PH_END()
+        // ---- phase 3: (A1, B1); stage A0 of tile kt+2
+        read_a(bufE, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) stage_half(0, hA0, kt + 2);
+        OVMR_PH_MID((void)0)
+        quadrant(1, 1, fb1);
+        OVMR_PH_END()
+        // ---- phase 4: (A1, B0), no fragment reads; stage B1 of tile kt+2; the odd tile must have landed: everything up to
+        //      phase 1's A1 -- three younger half-tiles (6 instructions) may stay in flight
+        if (more) stage_half(0, hB1, kt + 2);
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        OVMR_PH_MID((void)0)
+        quadrant(1, 0, fb0);
+        OVMR_PH_END()
+        // ---- phase 5: (A0, B0) of the odd tile; stage A1 of tile kt+2
+        read_b(bufO, 0, fb0);
+        __builtin_amdgcn_sched_barrier(0);
+        read_a(bufO, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) stage_half(0, hA1, kt + 2);
+        OVMR_PH_MID(asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory"))
+        quadrant(0, 0, fb0);
+        OVMR_PH_END()
+        // ---- phase 6: (A0, B1); stage B0 of tile kt+3
+        read_b(bufO, 1, fb1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) stage_half(1, hB0, kt + 3);
+        OVMR_PH_MID((void)0)
+        quadrant(0, 1, fb1);
+        OVMR_PH_END()
+        // ---- phase 7: (A1, B1); stage A0 of tile kt+3
+        read_a(bufO, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) stage_half(1, hA0, kt + 3);
+        OVMR_PH_MID((void)0)
+        quadrant(1, 1, fb1);
+        OVMR_PH_END()
+        // ---- phase 8: (A1, B0); stage B1 of tile kt+3; tile kt+2 must have landed (everything up to phase 5's A1)
+        if (more) stage_half(1, hB1, kt + 3);
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        OVMR_PH_MID((void)0)
+        quadrant(1, 0, fb0);
+        OVMR_PH_END()
+    }
+    if (wm == 0) __builtin_amdgcn_s_barrier();          // balances the extra barrier of the second wave row
+    __builtin_amdgcn_sched_barrier(0);
+#undef OVMR_PH_MID
+#undef OVMR_PH_END
+    } else
     if (OPT & 4) {
     // K loop with the iteration boundary moved INSIDE the MFMA stream.  All of a K-tile's fragment reads are issued two steps
     // before its last MFMAs, so the wait for the next tile's LDS-DMA, the workgroup barrier, the next tile's first six fragment
@@ -472,7 +657,10 @@ int launch_v5(const GemmArgs& a, hipStream_t s) {
         if (force < 0) { const char* e = getenv("OVMR_NT_STORE"); force = e ? atoi(e) : 0; }
         b.nt_store = force ? force : (b.epi != EPI_BIAS_RES && (size_t)b.M * b.N * 2 >= ((size_t)48 << 20) ? 2 : 1);
     }
-    if constexpr (OPT == 0 && (EPI == EPI_LN_BIAS || EPI == EPI_LN_BIAS_QGELU)) {
+    constexpr int P8 = OPT & 16;                        // 8-phase ping-pong K loop (256-row tiles; it replaces the OPT & 4 loop there)
+    constexpr bool PLAIN = (OPT & ~16) == 0;
+    constexpr bool OV_OK = !(P8 && MT == 8);
+    if constexpr (PLAIN && OV_OK && (EPI == EPI_LN_BIAS || EPI == EPI_LN_BIAS_QGELU)) {
         // the LayerNorm-folding launches also run the K loop with the boundary inside the MFMA stream (qkv_ln 354 -> 343 us,
         // c_fc_ln 525 -> 518 us; the plain bias / QuickGELU launches of the same shapes do not gain)
         static int ov_force = -1;
@@ -482,8 +670,16 @@ int launch_v5(const GemmArgs& a, hipStream_t s) {
             return launch_v5_k<EPI, MT, 4>(b, tiles_m, tiles_n, s);
         }
     }
-    if (OPT == 0 && b.nt_store == 2) return launch_v5_k<EPI, MT, 512>(b, tiles_m, tiles_n, s);
-    if constexpr (OPT == 0 && EPI == EPI_BIAS_RES) {
+    if constexpr (PLAIN && EPI != EPI_BIAS_RES) {
+        static int a_nt_all = -1;                       // experiment: OVMR_A_NT=3 -> nontemporal A stream on every epilogue
+        if (a_nt_all < 0) { const char* e = getenv("OVMR_A_NT"); a_nt_all = e && atoi(e) == 3; }
+        if (a_nt_all) {
+            if (b.nt_store == 2) return launch_v5_k<EPI, MT, P8 | 1 | 512>(b, tiles_m, tiles_n, s);
+            return launch_v5_k<EPI, MT, P8 | 1>(b, tiles_m, tiles_n, s);
+        }
+        if (b.nt_store == 2) return launch_v5_k<EPI, MT, P8 | 512>(b, tiles_m, tiles_n, s);
+    }
+    if constexpr (PLAIN && EPI == EPI_BIAS_RES) {
         // Residual projections.
         // (1) N <= 1024 (at most four N tiles share an A panel): the A stream is loaded with the nontemporal policy so that it
         //     does not push the W panels every tile re-reads out of the L2 (out_proj 146 -> 141 us, c_proj 477 -> 459 us).  With
@@ -494,10 +690,10 @@ int launch_v5(const GemmArgs& a, hipStream_t s) {
         if (a_nt_force < 0) { const char* e = getenv("OVMR_A_NT"); a_nt_force = e ? atoi(e) : 0; }       // 1 = never, 2 = always
         if (ov_force < 0) { const char* e = getenv("OVMR_K_OVERLAP"); ov_force = e ? atoi(e) : 0; }      // 1 = never, 2 = always
         const bool a_nt = a_nt_force != 1 && (a_nt_force == 2 || (tiles_n <= 4 && tiles_m * tiles_n >= 512));
-        const bool ov = ov_force != 1 && (ov_force == 2 || b.K >= 2048);
+        const bool ov = OV_OK && ov_force != 1 && (ov_force == 2 || b.K >= 2048);
         if (a_nt && ov) return launch_v5_k<EPI, MT, 5>(b, tiles_m, tiles_n, s);
         if (ov) return launch_v5_k<EPI, MT, 4>(b, tiles_m, tiles_n, s);
-        if (a_nt) return launch_v5_k<EPI, MT, 1>(b, tiles_m, tiles_n, s);
+        if (a_nt) return launch_v5_k<EPI, MT, P8 | 1>(b, tiles_m, tiles_n, s);
     }
     return launch_v5_k<EPI, MT, OPT>(b, tiles_m, tiles_n, s);
 }
@@ -550,6 +746,7 @@ int launch_gemm_f16_v5(const GemmArgs& a, int variant, hipStream_t s) {
     switch (variant) {
         case 18: return a.epi == EPI_BIAS_QGELU ? pick_v5<EPI_BIAS_QGELU, 64>(a, s) : pick_v5<EPI_BIAS, 64>(a, s);
         case 19: return pick_v5<EPI_BIAS, 128>(a, s);
+        case 8: return (a.K % 128) == 0 ? dispatch_v5<16>(a, s) : dispatch_v5<0>(a, s);   // 8-phase K loop: two K-tiles per iteration
         default: return dispatch_v5<0>(a, s);
     }
 }

@@ -93,6 +93,17 @@ def test_gemm_f16(lib, variant, M, N, K, epi):
     assert float(((got - ref).abs() > tol / 8).float().mean()) < 0.02
 
 
+@pytest.mark.parametrize("variant", [6, 8])
+@pytest.mark.parametrize("M,N,K,epi", [
+    (4096, 1024, 768, EPI_BIAS_QGELU), (2500, 2304, 768, EPI_BIAS), (5500, 768, 3072, EPI_BIAS_RES), (4096, 1000, 512, EPI_SCALE),
+    (30 * 196, 768, 768, EPI_PATCH), (16400, 256, 128, EPI_NONE), (4097, 1280, 640, EPI_BIAS), (8200, 768, 256, EPI_BIAS_RES),
+])
+def test_gemm_f16_large_tiles(lib, variant, M, N, K, epi):
+    """Shapes with >= 64 tiles of 256 x 256, which take the 256-row tile kernels (variant 6: double-buffered K loop; variant 8:
+    8-phase ping-pong K loop; K = 640 has an odd number of K-tiles and must fall back), incl. ragged M / N edges."""
+    test_gemm_f16(lib, variant, M, N, K, epi)
+
+
 @pytest.mark.parametrize("M,N,K,epi", [(36, 384, 128, EPI_BIAS), (288, 1536, 512, EPI_BIAS), (288, 512, 2048, EPI_BIAS_RES),
                                        (1000, 2048, 512, EPI_BIAS_QGELU), (7, 128, 512, EPI_BIAS_RES)])
 def test_gemm_f32(lib, M, N, K, epi):
@@ -166,10 +177,11 @@ def test_attention_f32(lib, B, L, H):
     np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), atol=2e-5, rtol=1e-4)
 
 
-@pytest.mark.parametrize("variant", [6, 0])          # 0: the dispatcher must route LN-folding GEMMs to the v5 kernel itself
+@pytest.mark.parametrize("variant", [6, 8, 0])       # 0: the dispatcher must route LN-folding GEMMs to the v5 kernel itself
 @pytest.mark.parametrize("M,D,K1,N2,qgelu,produce", [
     (197 * 3, 768, 768, 2304, 0, True), (1000, 768, 3072, 3072, 1, True), (256, 256, 64, 128, 0, True),
     (513, 512, 2048, 1536, 0, True), (300, 1024, 1024, 4096, 1, True), (462, 512, 0, 2048, 1, False),
+    (197 * 28, 768, 768, 3072, 1, True), (5600, 768, 3072, 2304, 0, True),          # >= 64 tiles: the 256-row tile kernels
 ])
 def test_gemm_layernorm_fold(lib, variant, M, D, K1, N2, qgelu, produce):
     """EPI_BIAS_RES with the statistics epilogue, then LayerNorm folded into the next GEMM (common.h EPI_LN_BIAS):
