@@ -52,6 +52,8 @@ def parse():
     ap.add_argument("--cpu-sample-classes", type=int, default=2, help="classes per CPU worker process and repetition (0: skip)")
     ap.add_argument("--cpu-threads", type=int, default=16, help="threads per CPU worker process")
     ap.add_argument("--cpu-reps", type=int, default=3)
+    ap.add_argument("--cpu-procs", type=int, default=0, help="CPU worker processes (0: usable CPUs // --cpu-threads)")
+    ap.add_argument("--cpu-timeout", type=float, default=240.0, help="give up on the CPU baseline after this many seconds")
     return ap.parse_args()
 
 
@@ -162,7 +164,7 @@ def main():
         cpu = cpu_baseline(spec, sd, pl, tok, args, n_ctx) if args.cpu_sample_classes > 0 else None   # 0: profiling runs skip the CPU leg
 
     if rank == 0:
-        flops_img = eng.flops_per_image()
+        flops_img, flops_run = eng.flops_per_image(), eng.flops_per_image_executed()
         line = {
             "metric": "images/sec ViT-B/16 encode+fusion, 1k-class×16-shot, 1/2/4/8 MI355X",
             "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -178,8 +180,9 @@ def main():
             "phases": {"generation_images_per_s_rank0": round((c1 - c0) * S / tg, 1),
                        "inference_images_per_s_rank0": round((q1 - q0) / ti, 1) if q1 > q0 else None,
                        "inference_query_batch": args.query_batch,
-                       "encoder_tflops_e2e": round(value * flops_img / 1e12, 1),
-                       "e2e_frac_of_fp16_mfma_peak": round(value * flops_img / 1e12 / (2500.0 * world), 4)},
+                       "encoder_tflops_e2e_algorithmic": round(value * flops_img / 1e12, 1),
+                       "encoder_tflops_e2e_executed": round(value * flops_run / 1e12, 1),
+                       "e2e_frac_of_fp16_mfma_peak": round(value * flops_run / 1e12 / (2500.0 * world), 4)},
         }
         if cpu and cpu.get("value"):
             line["gpu_over_cpu"] = round(value / cpu["value"], 1)
@@ -344,12 +347,35 @@ def _cpu_worker(widx, nproc, threads, spec_name, sd16, pl, tok, shots, classes, 
     with torch.no_grad():
         for sdx, prec, x, qx, out in ((sd32, "fp32", img, q, times32), (sd16, "fp16", img.half(), q.half(), times16)):
             for rep in range(reps + 1):                              # rep 0 = warm-up
-                barrier.wait()
+                barrier.wait(timeout=600)
                 t0 = time.perf_counter()
                 job(sdx, prec, x, qx)
                 if rep:
                     out.append(time.perf_counter() - t0)
     queue.put((widx, times32, times16))
+
+
+def effective_cpus():
+    """CPUs this process may actually use: the affinity mask, capped by the cgroup CPU quota (os.cpu_count() reports the
+    machine, not the container's share: a 256-thread pool on a 32-CPU quota runs ~300x slower than a 16-thread one)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:                      # cgroup v2: "<quota> <period>" or "max <period>"
+            q, per = f.read().split()
+            if q != "max":
+                quota = float(q) / float(per)
+    except Exception:
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as g:
+                q, per = float(f.read()), float(g.read())
+                if q > 0:
+                    quota = q / per
+        except Exception:
+            pass
+    if quota is not None:
+        n = max(1, min(n, int(quota)))
+    return n, quota
 
 
 def cpu_baseline(spec, sd, pl, tok, args, n_ctx):
@@ -362,24 +388,48 @@ def cpu_baseline(spec, sd, pl, tok, args, n_ctx):
     import torch
     import torch.multiprocessing as mp
     from oracle import ovmr_oracle as O
-    cores = os.cpu_count()
+    cores, quota = effective_cpus()
     threads = max(1, min(args.cpu_threads, cores))
     nproc = max(1, cores // threads)
+    if args.cpu_procs > 0:
+        nproc = args.cpu_procs
     S, Cs = args.shots, args.cpu_sample_classes
     sd16 = O.convert_weights({k: v.detach().float().cpu() for k, v in sd.items()}, "fp16")
     for v in sd16.values():
         v.share_memory_()
     cpu_pl = {k: v.detach().float().cpu().share_memory_() for k, v in pl.items()}
     ctx = mp.get_context("spawn")                                  # this process has initialised the GPU: no fork
-    barrier, queue = ctx.Barrier(nproc), ctx.SimpleQueue()
+    barrier, queue = ctx.Barrier(nproc), ctx.Queue()
     t_all = time.perf_counter()
     procs = [ctx.Process(target=_cpu_worker, args=(i, nproc, threads, spec.name, sd16, cpu_pl, tok[:nproc * Cs].clone(), S, Cs,
                                                    args.cpu_reps, n_ctx, barrier, queue)) for i in range(nproc)]
+    saved_env = {k: os.environ.get(k) for k in ("OMP_NUM_THREADS", "MKL_NUM_THREADS")}
+    os.environ.update(OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads))   # children size their pools at import
+    try:
+        for p in procs:
+            p.start()
+    finally:
+        for k, v in saved_env.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    res, deadline = [], time.time() + args.cpu_timeout
+    try:
+        while len(res) < nproc:
+            try:
+                res.append(queue.get(timeout=5))
+            except Exception:
+                dead = [p for p in procs if p.exitcode not in (None, 0)]
+                if dead or time.time() > deadline:
+                    raise RuntimeError(f"{len(dead)} CPU worker(s) failed" if dead else "CPU baseline timed out")
+    except RuntimeError as e:
+        for p in procs:
+            if p.is_alive():
+                p.terminate()
+        return {"value": None, "unit": "images/s", "cores": nproc * threads, "kind": "port", "sample": f"not measured: {e}"}
     for p in procs:
-        p.start()
-    res = [queue.get() for _ in procs]
-    for p in procs:
-        p.join()
+        p.join(timeout=30)
     t_all = time.perf_counter() - t_all
     n_img = Cs * S + 4
     per32 = [n_img / statistics.median(t) for _, t, _ in res]
@@ -396,7 +446,7 @@ def cpu_baseline(spec, sd, pl, tok, args, n_ctx):
                       f"(batch {Cs * S}) on its own class slice, 1 warm-up + {args.cpu_reps} timed repetitions, median; whole host "
                       f"fp32 math on fp16-rounded weights {v32:.1f} img/s, fp16 {v16:.1f} img/s, faster reported; "
                       f"{t_all:.0f} s wall incl. process start",
-            "host_cores": cores, "cpu_model": model, "processes": nproc, "threads_per_process": threads,
+            "host_cores": os.cpu_count(), "usable_cpus": cores, "cgroup_cpu_quota": quota, "cpu_model": model, "processes": nproc, "threads_per_process": threads,
             "per_process_images_per_s": round(statistics.median(per32 if v32 >= v16 else per16), 3),
             "fp16_images_per_s": round(v16, 2), "fp32_images_per_s": round(v32, 2)}
 

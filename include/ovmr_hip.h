@@ -144,8 +144,12 @@ int ovmr_zeroshot_logits(ovmr_handle* h, const void* feats_f16, int B, const voi
 /* exp(logit_scale) as held by the handle (set through ovmr_set_weight("logit_scale")). */
 float ovmr_logit_scale(const ovmr_handle* h);
 
-/* Closed-form FLOP counts used for every roofline fraction. */
+/* Closed-form FLOP counts.  ovmr_flops_per_image is the ALGORITHMIC count of the reference's
+ * VisionTransformer.forward (every block over every token, clip/model.py:411-428: 35.127 GFLOP for ViT-B/16);
+ * ovmr_flops_per_image_executed is what ovmr_encode_image launches: its last block runs attention / out_proj / MLP for the
+ * CLS query row only (identical result), ~6 % fewer. */
 double ovmr_flops_per_image(const ovmr_handle* h);
+double ovmr_flops_per_image_executed(const ovmr_handle* h);
 double ovmr_flops_per_prompt(const ovmr_handle* h, int seq_len);
 
 /* Unit-test hooks: launch ONE kernel (no handle).  f32 selects the fp32 (aggregator) kernels;

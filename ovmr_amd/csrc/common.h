@@ -28,6 +28,10 @@ enum {
     // instead -- same magnitude of error, one full read + write of the activations less per LayerNorm.
     EPI_LN_BIAS = 6,        // C = h(LN-folded acc)                  ln_1 + in_proj       (clip/model.py:192)
     EPI_LN_BIAS_QGELU = 7,  // u = h(LN-folded acc); C = u * sigmoid(1.702u)   ln_2 + c_fc + QuickGELU (clip/model.py:193)
+    // Cross-validation logits that are never written (gemm_f16_v5 only): u = h(h(acc) * scale) as EPI_SCALE, then per row
+    // the (maximum, lowest column holding it) of the tile's 256 columns -> argmax_out[m][tn] = {max as float, column};
+    // launch_argmax_reduce finishes the row argmax over the N tiles and counts.      (trainers/mm_classifier_one_prompt.py:263-270)
+    EPI_SCALE_ARGMAX = 8,
 };
 
 struct GemmArgs {
@@ -50,6 +54,7 @@ struct GemmArgs {
     const float* ln_g; const float* ln_b;  // EPI_LN_*: [N] fp32 each
     float* stats_out;                      // EPI_BIAS_RES, optional: partial statistics of the stored C rows, [M][N/256][2]
     int nt_store;                          // v5: 0 = auto (streaming stores when C is much larger than the L2s), 1 = never, 2 = always
+    float* argmax_out;                     // EPI_SCALE_ARGMAX: [M][ceil(N/256)][2] (value, column index bits)
 };
 
 __device__ __forceinline__ float quick_gelu_h(float u) {
@@ -129,6 +134,7 @@ int launch_agg_output(const float* x, float* tokens, int Cb, int La, int n_ctx, 
 int launch_assemble_prompts(const half_t* base, const int64_t* labels, const float* tokens, half_t* out,
                             int Cb, int Lctx, int n_ctx, int D, hipStream_t s);
 int launch_argmax_counts(const half_t* logits, int ld, const int* labels, int R, int C, int* tp, int* n_pred, hipStream_t s);
+int launch_argmax_reduce(const float* partial, int tiles, const int* labels, int R, int C, int* tp, int* n_pred, hipStream_t s);
 int launch_fusion_weights(const int* counts, const int* n_label, int C, float tau, float* out, hipStream_t s);
 int launch_scale_f16(const half_t* x, half_t* y, float scale, long n, hipStream_t s);
 int launch_fused_softmax(const half_t* l0, const half_t* l1, const half_t* l2, const float* w, int n_mod,

@@ -36,6 +36,28 @@ __global__ __launch_bounds__(256) void xval_argmax_counts(const half_t* __restri
     }
 }
 
+// Second stage of the fused logits GEMM + row argmax (EPI_SCALE_ARGMAX, gemm_f16_v5.hip): partial[row][tile] = {maximum of
+// the tile's columns, lowest column holding it}; the row's argmax is the largest value, ties to the lowest column -- the same
+// answer as one argmax over the whole fp16 logits row -- followed by the same two histogram updates.
+__global__ __launch_bounds__(256) void xval_argmax_reduce(const float* __restrict__ partial, int tiles,
+                                                          const int* __restrict__ labels, int rows, int C,
+                                                          int* __restrict__ tp, int* __restrict__ n_pred) {
+    const int row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= rows) return;
+    const float2_t* p = (const float2_t*)partial + (long)row * tiles;
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int t = 0; t < tiles; ++t) {                 // tiles in increasing column order: strict > keeps the lowest column
+        const float2_t v = p[t];
+        const int c = __builtin_bit_cast(int, v[1]);
+        if (v[0] > best || bi == 0x7fffffff) { best = v[0]; bi = c; }
+    }
+    if (bi < C) {
+        atomicAdd(n_pred + bi, 1);
+        if (bi == labels[row]) atomicAdd(tp + bi, 1);
+    }
+}
+
 // counts: int32 [3][2][C] = {mm, vision, text} x {tp, n_pred}; n_label: int32 [C]
 __global__ void fusion_weights_kernel(const int* __restrict__ counts, const int* __restrict__ n_label, int C,
                                       float tau, float* __restrict__ out) {
@@ -102,6 +124,12 @@ __global__ __launch_bounds__(256) void fused_softmax_kernel(const half_t* __rest
 int launch_argmax_counts(const half_t* logits, int ld, const int* labels, int R, int C, int* tp, int* n_pred, hipStream_t s) {
     if (R <= 0) return 0;
     hipLaunchKernelGGL(xval_argmax_counts, dim3((R + 3) / 4), dim3(256), 0, s, logits, ld, labels, R, C, tp, n_pred);
+    return (int)hipGetLastError();
+}
+
+int launch_argmax_reduce(const float* partial, int tiles, const int* labels, int R, int C, int* tp, int* n_pred, hipStream_t s) {
+    if (R <= 0) return 0;
+    hipLaunchKernelGGL(xval_argmax_reduce, dim3((R + 255) / 256), dim3(256), 0, s, partial, tiles, labels, R, C, tp, n_pred);
     return (int)hipGetLastError();
 }
 

@@ -135,6 +135,10 @@ int launch_gemm_f16(const GemmArgs& a, int variant, hipStream_t s) {
     if (a.M <= 0 || a.N <= 0) return 0;
     if (a.K <= 0 || (a.K % BK) != 0 || (a.lda & 7) || (a.ldw & 7)) return -2;  // caller pads K to 64
     const bool v5_variant = (variant >= 5 && variant <= 8) || variant == 18 || variant == 19;
+    if (a.epi == EPI_SCALE_ARGMAX) {                                            // only the v5 kernel; -4: shape not supported
+        const int rc = launch_gemm_f16_v5(a, v5_variant ? variant : 6, s);
+        return rc == -100 ? -4 : rc;
+    }
     if (a.epi == EPI_LN_BIAS || a.epi == EPI_LN_BIAS_QGELU || a.stats_out) {   // only the v5 kernel folds LayerNorm
         const int rc = launch_gemm_f16_v5(a, v5_variant ? variant : 6, s);
         return rc == -100 ? -4 : rc;

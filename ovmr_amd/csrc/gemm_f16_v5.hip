@@ -467,6 +467,47 @@ __global__ __launch_bounds__(512) void gemm_f16_v5_kernel(GemmArgs a, int tiles_
         if (sum == 12345.678f) C[tid] = (half_t)sum;
         return;
     }
+    if constexpr (EPI == EPI_SCALE_ARGMAX) {
+        // Logits that are never stored: u = h(h(acc) * scale) exactly as EPI_SCALE, then per row the maximum of this tile's
+        // columns and the LOWEST column holding it.  A row's 64 columns of one wave sit in four lanes (fg) x 16 values;
+        // lanes walk their columns in increasing order, so a strict > keeps the first maximum; lanes and the four column
+        // waves are merged with ties to the lower column.
+        __syncthreads();                                               // every wave is done with the K buffers
+        float2_t* arg_lds = (float2_t*)smem;                           // [BM rows][4 column waves]
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            float bv = -INFINITY;
+            int bc = 0x7fffffff;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int c0 = n0 + wn * 64 + j * 16 + fg * 4;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float u = (float)(half_t)((float)(half_t)acc[i][j][r] * a.scale);
+                    if (c0 + r < a.N && (u > bv || bc == 0x7fffffff)) { bv = u; bc = c0 + r; }
+                }
+            }
+#pragma unroll
+            for (int o = 16; o <= 32; o <<= 1) {
+                const float ov = __shfl_xor(bv, o, 64);
+                const int oc = __shfl_xor(bc, o, 64);
+                if (ov > bv || (ov == bv && oc < bc)) { bv = ov; bc = oc; }
+            }
+            if (fg == 0) arg_lds[(wm * (BM / 2) + i * 16 + fr) * 4 + wn] = (float2_t){bv, __builtin_bit_cast(float, bc)};
+        }
+        __syncthreads();
+        if (tid < BM && m0 + tid < a.M) {
+            float2_t best = arg_lds[tid * 4];
+#pragma unroll
+            for (int w = 1; w < 4; ++w) {                               // column waves in increasing column order
+                const float2_t v = arg_lds[tid * 4 + w];
+                const int vc = __builtin_bit_cast(int, v[1]), bcc = __builtin_bit_cast(int, best[1]);
+                if (v[0] > best[0] || (v[0] == best[0] && vc < bcc)) best = v;
+            }
+            *(float2_t*)(a.argmax_out + ((long)(m0 + tid) * tiles_n + tn) * 2) = best;
+        }
+        return;
+    }
     char* et = smem + wave * (64 * EP);                 // this wave's 64-row x 64-column staging tile
     const int er = lane >> 3, ec = (lane & 7) * 8;     // phase 2: row within an 8-row group, first column
     const bool emit_stats = EPI == EPI_BIAS_RES && a.stats_out != nullptr;
@@ -728,6 +769,7 @@ int dispatch_v5(const GemmArgs& a, hipStream_t s) {
         case EPI_SCALE: return pick_v5<EPI_SCALE, OPT>(a, s);
         case EPI_LN_BIAS: return pick_v5<EPI_LN_BIAS, OPT>(a, s);
         case EPI_LN_BIAS_QGELU: return pick_v5<EPI_LN_BIAS_QGELU, OPT>(a, s);
+        case EPI_SCALE_ARGMAX: return pick_v5<EPI_SCALE_ARGMAX, OPT>(a, s);
     }
     return -3;
 }
@@ -736,6 +778,10 @@ int dispatch_v5(const GemmArgs& a, hipStream_t s) {
 
 // variant 6: the default; 18 / 19: timing-only epilogue ablations (no global stores / no epilogue at all)
 int launch_gemm_f16_v5(const GemmArgs& a, int variant, hipStream_t s) {
+    if (a.epi == EPI_SCALE_ARGMAX) {
+        if (a.M < 256 || a.N < 128 || !a.argmax_out || (long)a.M * a.lda * 2 >= 0x7fffffffL || (long)a.N * a.ldw * 2 >= 0x7fffffffL)
+            return -100;
+    } else
     if (a.M < 256 || a.N < 128 || (a.N & 7) || (a.ldc & 7) || (a.epi == EPI_BIAS_RES && (a.ldres & 7)) ||
         ((uintptr_t)a.C & 15) || (a.epi == EPI_BIAS_RES && ((uintptr_t)a.res & 15)) ||
         (long)a.M * a.lda * 2 >= 0x7fffffffL || (long)a.N * a.ldw * 2 >= 0x7fffffffL)

@@ -42,6 +42,7 @@ struct ovmr_handle {
     bool finalized = false;
     int gemm_variant = 6, attn_variant = 1;   // defaults = fastest verified kernels (tools/gemm_bench.py)
     int ln_fold = 1;                          // fold ln_1 / ln_2 of the fp16 towers into the consuming GEMM where the shape allows
+    int xval_fused = 1;                       // cross-validation logits: row argmax fused into the GEMM epilogue (never stored)
     float logit_scale_exp = 100.f;
     bool have_logit_scale = false;
 
@@ -273,6 +274,7 @@ int ovmr_set_option(ovmr_handle* h, const char* key, int value) {
     if (!strcmp(key, "gemm")) h->gemm_variant = value;
     else if (!strcmp(key, "attn")) h->attn_variant = value;
     else if (!strcmp(key, "ln_fold")) h->ln_fold = value;
+    else if (!strcmp(key, "xval_fused")) h->xval_fused = value;
     else return fail(h, OVMR_E_NAME, "unknown option '%s'", key);
     return 0;
 }
@@ -574,9 +576,28 @@ int ovmr_xval_counts(ovmr_handle* h, const void* feats_f16, const int32_t* label
     if (!h->finalized) return fail(h, OVMR_E_STATE, "ovmr_finalize() has not been called");
     hipStream_t s = (hipStream_t)stream;
     const int D = h->d.embed_dim;
-    const int chunk = (int)std::min<long>(std::max<long>(64, h->logit_elems_cap / C), 1L << 20);
     Carver c(h->ws);
     half_t* logits = c.take<half_t>((size_t)h->logit_elems_cap);
+    if (h->xval_fused && R >= 256 && C >= 128) {
+        // K18 + K19 fused: the [R, C] logits never reach HBM.  The GEMM epilogue leaves one
+        // (maximum, lowest column) pair per row and 256-column tile; a row kernel finishes the argmax and counts.
+        const int tiles = (C + 255) / 256;
+        float* partial = (float*)logits;                                  // 2 floats per (row, tile) in the logits workspace
+        const long cap_rows = std::min<long>(std::max<long>(512, h->logit_elems_cap / (4L * tiles)), 1L << 22);
+        if (cap_rows * tiles * 8 > h->logit_elems_cap * 2) return fail(h, OVMR_E_SHAPE, "class count %d too large for the logits workspace", C);
+        const long n_chunks = (R + cap_rows - 1) / cap_rows;              // balanced chunks: each has > cap_rows / 2 >= 256 rows
+        for (long i = 0, r0 = 0; i < n_chunks; ++i) {
+            const int Rc = (int)(R / n_chunks + (i < R % n_chunks ? 1 : 0));
+            GemmArgs g = gemm((const half_t*)feats_f16 + (size_t)r0 * D, D, clf_f16, D, nullptr, C, Rc, C, D, EPI_SCALE_ARGMAX);
+            g.scale = h->logit_scale_exp;
+            g.argmax_out = partial;
+            CK(launch_gemm_f16(g, h->gemm_variant, s));
+            CK(launch_argmax_reduce(partial, tiles, labels + r0, Rc, C, tp, n_pred, s));
+            r0 += Rc;
+        }
+        return 0;
+    }
+    const int chunk = (int)std::min<long>(std::max<long>(64, h->logit_elems_cap / C), 1L << 20);
     for (int r0 = 0; r0 < R; r0 += chunk) {
         const int Rc = std::min(chunk, R - r0);
         if ((long)Rc * C > h->logit_elems_cap) return fail(h, OVMR_E_SHAPE, "class count %d too large for the logits workspace", C);
@@ -654,6 +675,16 @@ double ovmr_flops_per_image(const ovmr_handle* h) {
     const ovmr_model_desc& d = h->d;
     const double G2 = (double)h->G * h->G, W = d.vision_width, K = 3.0 * d.vision_patch_size * d.vision_patch_size;
     return 2.0 * G2 * K * W + tower_flops(h->L, W, d.vision_layers) + 2.0 * W * d.embed_dim;
+}
+double ovmr_flops_per_image_executed(const ovmr_handle* h) {
+    if (!h) return 0;
+    const ovmr_model_desc& d = h->d;
+    const double L = h->L, W = d.vision_width;
+    // last block as launched: K/V/Q projection of all tokens (6 L W^2), then one query row: scores + PV (4 L W), out_proj
+    // (2 W^2), MLP (16 W^2)
+    const double last_full = 24.0 * L * W * W + 4.0 * L * L * W;
+    const double last_run = 6.0 * L * W * W + 4.0 * L * W + 18.0 * W * W;
+    return ovmr_flops_per_image(h) - last_full + last_run;
 }
 double ovmr_flops_per_prompt(const ovmr_handle* h, int seq_len) {
     if (!h) return 0;

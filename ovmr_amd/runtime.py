@@ -52,6 +52,7 @@ SIGNATURES = {
     "ovmr_zeroshot_logits": (c_i, [c_p, c_p, c_i, c_p, c_i, c_p, c_p]),
     "ovmr_logit_scale": (ctypes.c_float, [c_p]),
     "ovmr_flops_per_image": (ctypes.c_double, [c_p]),
+    "ovmr_flops_per_image_executed": (ctypes.c_double, [c_p]),
     "ovmr_flops_per_prompt": (ctypes.c_double, [c_p, c_i]),
     "ovmr_debug_gemm": (c_i, [c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, ctypes.c_float, c_i, c_i, c_p]),
     "ovmr_debug_lnfold": (c_i, [c_i, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_i, c_i, c_p, c_p, c_p]),
@@ -176,6 +177,9 @@ class Engine:
     def flops_per_image(self) -> float:
         return float(self.lib.ovmr_flops_per_image(self.h))
 
+    def flops_per_image_executed(self) -> float:
+        return float(self.lib.ovmr_flops_per_image_executed(self.h))
+
     def flops_per_prompt(self, seq_len: int) -> float:
         return float(self.lib.ovmr_flops_per_prompt(self.h, seq_len))
 
@@ -193,6 +197,9 @@ class Engine:
 
     def encode_text_embedded(self, prompts: torch.Tensor, index: torch.Tensor, seq_len: Optional[int] = None,
                              normalize: int = 0) -> torch.Tensor:
+        sl_req = int(seq_len) if seq_len is not None else self.spec.context_length
+        if isinstance(index, torch.Tensor) and not index.is_cuda and index.numel() and int(index.max()) >= sl_req:
+            raise ValueError(f"seq_len {sl_req} does not reach the largest read-out index {int(index.max())}")
         prompts = self._dev(prompts, torch.float16)
         index = self._dev(index, torch.int32)
         N = prompts.shape[0]
@@ -203,6 +210,10 @@ class Engine:
         return out
 
     def encode_text_ids(self, ids: torch.Tensor, seq_len: Optional[int] = None, normalize: int = 0) -> torch.Tensor:
+        if seq_len is not None and isinstance(ids, torch.Tensor) and not ids.is_cuda and ids.numel():
+            eot = int(ids.argmax(dim=-1).max())                 # EOT has the largest id (clip/model.py:831)
+            if eot >= int(seq_len):
+                raise ValueError(f"seq_len {int(seq_len)} does not reach the EOT token at position {eot}")
         ids = self._dev(ids, torch.int64)
         N = ids.shape[0]
         out = torch.empty((N, self.spec.embed_dim), dtype=torch.float16, device=self.device)

@@ -632,3 +632,30 @@ def test_mm_cls_op_trainer_shim(tmp_path, O, monkeypatch):
     for k in ("text_classifier", "vision_classifier", "mm_classifier"):
         assert_cosine(saved[k].numpy(), r[k].numpy(), COS_TOL, k)
     modules._DEFAULT_TOKENIZER.clear()
+
+
+@pytest.mark.parametrize("C,R,D_name", [(130, 300, "tiny"), (1000, 16000, "small"), (1003, 4097, "tiny"), (6000, 2600, "tiny"), (256, 256, "tiny")])
+def test_xval_fused_argmax_equals_materialised_logits(C, R, D_name):
+    """K18 + K19 fused (row argmax in the logits GEMM's epilogue, the [R, C] logits never written) against the path that
+    materialises the fp16 logits and runs the argmax kernel on them: identical counters, incl. exact ties (duplicated class
+    rows: the lowest index must win in both) and ragged last column tiles."""
+    e = _clip(D_name).engine(2)
+    D = synth.SPECS[D_name].embed_dim
+    g = torch.Generator().manual_seed(C + R)
+    clf = torch.nn.functional.normalize(torch.randn(C, D, generator=g), dim=-1).half()
+    clf[C // 2] = clf[C // 3]                               # exact ties inside one tile or across tiles
+    clf[C - 1] = clf[1]
+    lab = torch.randint(0, C, (R,), generator=g, dtype=torch.int32)
+    feats = torch.nn.functional.normalize(clf[lab.long()].float() + 0.4 * torch.randn(R, D, generator=g), dim=-1).half()
+    out = {}
+    try:
+        for fused in (1, 0):
+            e.set_option("xval_fused", fused)
+            counts = torch.zeros((2, C), dtype=torch.int32, device="cuda")
+            e.xval_counts(feats, lab, clf, counts[0], counts[1])
+            out[fused] = counts.cpu()
+    finally:
+        e.set_option("xval_fused", 1)
+    assert int(out[1][1].sum()) == R
+    assert torch.equal(out[0], out[1])
+    assert int(out[1][1][C - 1]) == 0 or C - 1 == 1        # the duplicate of row 1 never wins a tie
