@@ -154,13 +154,20 @@ __global__ __launch_bounds__(512, 4) void attn_f16_v1(const half_t* __restrict__
                 const int thr = (on[u] ? (CAUSAL ? min(L, q + 1) : L) : 0) - k0 - fg * 4;
 #pragma unroll
                 for (int nt = 0; nt < 4; ++nt)
+                    if (nt < ntv) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) s[u][nt][r] = (nt * 16 + r < thr) ? s[u][nt][r] : -INFINITY;
+                        for (int r = 0; r < 4; ++r) s[u][nt][r] = (nt * 16 + r < thr) ? s[u][nt][r] : -INFINITY;
+                    }
             }
+            // (r02) 16-key sub-tiles past the last valid key (L = 197: 3 of the 4 in the last key block) are skipped by the
+            // maximum / exponential / conversion passes too -- wave-uniform branches; their P is 0.  Before, the last block
+            // cost a full softmax pass for 5 valid keys: a quarter of this kernel's vector instructions.
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt)
+                if (nt < ntv) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[u][nt][r]);
+                    for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[u][nt][r]);
+                }
             mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
             const float mxs = mx * scale_log2e;
@@ -174,10 +181,15 @@ __global__ __launch_bounds__(512, 4) void attn_f16_v1(const half_t* __restrict__
             }
             const float m_ref = m_run[u];
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt)
+            for (int nt = 0; nt < 4; ++nt) {
+                if (nt < ntv) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    s[u][nt][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[u][nt][r], scale_log2e, -m_ref));
+                    for (int r = 0; r < 4; ++r)
+                        s[u][nt][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[u][nt][r], scale_log2e, -m_ref));
+                } else {
+                    s[u][nt] = zero;
+                }
+            }
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll

@@ -44,13 +44,15 @@ __global__ __launch_bounds__(256) void xval_argmax_reduce(const float* __restric
                                                           int* __restrict__ tp, int* __restrict__ n_pred) {
     const int row = blockIdx.x * blockDim.x + threadIdx.x;
     if (row >= rows) return;
-    const float2_t* p = (const float2_t*)partial + (long)row * tiles;
+    // pairs are read as two 32-bit integers (value bits, column): hipcc (ROCm 7.2) mis-selected the VALUE register for the
+    // column when the pair was loaded as a float2 and its second lane bit-cast to int
+    const int* p = (const int*)partial + (long)row * tiles * 2;
     float best = -INFINITY;
     int bi = 0x7fffffff;
     for (int t = 0; t < tiles; ++t) {                 // tiles in increasing column order: strict > keeps the lowest column
-        const float2_t v = p[t];
-        const int c = __builtin_bit_cast(int, v[1]);
-        if (v[0] > best || bi == 0x7fffffff) { best = v[0]; bi = c; }
+        const float v = __int_as_float(p[2 * t]);
+        const int c = p[2 * t + 1];
+        if (v > best || bi == 0x7fffffff) { best = v; bi = c; }
     }
     if (bi < C) {
         atomicAdd(n_pred + bi, 1);

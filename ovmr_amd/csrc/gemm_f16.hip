@@ -134,7 +134,7 @@ int launch_gemm_f16_v7(const GemmArgs& a, hipStream_t s);               // gemm_
 int launch_gemm_f16(const GemmArgs& a, int variant, hipStream_t s) {
     if (a.M <= 0 || a.N <= 0) return 0;
     if (a.K <= 0 || (a.K % BK) != 0 || (a.lda & 7) || (a.ldw & 7)) return -2;  // caller pads K to 64
-    const bool v5_variant = (variant >= 5 && variant <= 8) || variant == 18 || variant == 19;
+    const bool v5_variant = (variant >= 5 && variant <= 8) || variant == 18 || variant == 19 || variant == 28 || variant == 29;
     if (a.epi == EPI_SCALE_ARGMAX) {                                            // only the v5 kernel; -4: shape not supported
         const int rc = launch_gemm_f16_v5(a, v5_variant ? variant : 6, s);
         return rc == -100 ? -4 : rc;

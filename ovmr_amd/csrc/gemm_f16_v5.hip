@@ -473,7 +473,7 @@ __global__ __launch_bounds__(512) void gemm_f16_v5_kernel(GemmArgs a, int tiles_
         // lanes walk their columns in increasing order, so a strict > keeps the first maximum; lanes and the four column
         // waves are merged with ties to the lower column.
         __syncthreads();                                               // every wave is done with the K buffers
-        float2_t* arg_lds = (float2_t*)smem;                           // [BM rows][4 column waves]
+        int* arg_lds = (int*)smem;                                     // [BM rows][4 column waves][value bits, column]
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
             float bv = -INFINITY;
@@ -493,18 +493,25 @@ __global__ __launch_bounds__(512) void gemm_f16_v5_kernel(GemmArgs a, int tiles_
                 const int oc = __shfl_xor(bc, o, 64);
                 if (ov > bv || (ov == bv && oc < bc)) { bv = ov; bc = oc; }
             }
-            if (fg == 0) arg_lds[(wm * (BM / 2) + i * 16 + fr) * 4 + wn] = (float2_t){bv, __builtin_bit_cast(float, bc)};
+            if (fg == 0) {
+                int* d = arg_lds + ((wm * (BM / 2) + i * 16 + fr) * 4 + wn) * 2;
+                d[0] = __float_as_int(bv);
+                d[1] = bc;
+            }
         }
         __syncthreads();
         if (tid < BM && m0 + tid < a.M) {
-            float2_t best = arg_lds[tid * 4];
+            float bv = __int_as_float(arg_lds[tid * 8]);
+            int bc = arg_lds[tid * 8 + 1];
 #pragma unroll
             for (int w = 1; w < 4; ++w) {                               // column waves in increasing column order
-                const float2_t v = arg_lds[tid * 4 + w];
-                const int vc = __builtin_bit_cast(int, v[1]), bcc = __builtin_bit_cast(int, best[1]);
-                if (v[0] > best[0] || (v[0] == best[0] && vc < bcc)) best = v;
+                const float v = __int_as_float(arg_lds[tid * 8 + 2 * w]);
+                const int vc = arg_lds[tid * 8 + 2 * w + 1];
+                if (v > bv || (v == bv && vc < bc)) { bv = v; bc = vc; }
             }
-            *(float2_t*)(a.argmax_out + ((long)(m0 + tid) * tiles_n + tn) * 2) = best;
+            int* dst = (int*)a.argmax_out + ((long)(m0 + tid) * tiles_n + tn) * 2;
+            dst[0] = __float_as_int(bv);
+            dst[1] = bc;
         }
         return;
     }
@@ -686,7 +693,9 @@ int launch_v5(const GemmArgs& a, hipStream_t s) {
         if (force < 0) { const char* e = getenv("OVMR_N_GROUP"); force = e ? atoi(e) : 0; }
         // measured (profiles/r01e_gemm_experiments.md): groups of 4-6 raise the L2 hit rate of qkv / c_fc from 65-68 %
         // to 72-73 % but move the run time by < 2 %, and hurt c_proj; the default therefore stays row-major (G = all)
-        b.n_group = force > 0 ? std::min(force, tiles_n) : tiles_n;
+        // with the 8-phase K loop (r02c, same-process A/B at batch 512): groups of 4 N tiles take 1.5-2.5 % off qkv / c_fc
+        // (c_fc_ln 496 -> 484 us, qkv_ln 329 -> 325 us), nothing off the N = 768 shapes
+        b.n_group = force > 0 ? std::min(force, tiles_n) : (((OPT & 16) && MT == 8 && tiles_n >= 8) ? 4 : tiles_n);
     }
     if (b.nt_store == 0) {
         // C written with the nontemporal hint does not evict the A / W panels the other tiles of the XCD are streaming from
@@ -793,6 +802,8 @@ int launch_gemm_f16_v5(const GemmArgs& a, int variant, hipStream_t s) {
         case 18: return a.epi == EPI_BIAS_QGELU ? pick_v5<EPI_BIAS_QGELU, 64>(a, s) : pick_v5<EPI_BIAS, 64>(a, s);
         case 19: return pick_v5<EPI_BIAS, 128>(a, s);
         case 8: return (a.K % 128) == 0 ? dispatch_v5<16>(a, s) : dispatch_v5<0>(a, s);   // 8-phase K loop: two K-tiles per iteration
+        case 28: return a.epi == EPI_BIAS_QGELU ? pick_v5<EPI_BIAS_QGELU, 16 | 64>(a, s) : pick_v5<EPI_BIAS, 16 | 64>(a, s);   // timing-only: no stores
+        case 29: return pick_v5<EPI_BIAS, 16 | 128>(a, s);                                                                      // timing-only: no epilogue
         default: return dispatch_v5<0>(a, s);
     }
 }

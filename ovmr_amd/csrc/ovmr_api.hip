@@ -40,7 +40,7 @@ struct ovmr_handle {
     std::vector<void*> derived;   // layouts rebuilt by every ovmr_finalize
     std::string err;
     bool finalized = false;
-    int gemm_variant = 6, attn_variant = 1;   // defaults = fastest verified kernels (tools/gemm_bench.py)
+    int gemm_variant = 8, attn_variant = 1;   // defaults = fastest verified kernels (tools/gemm_bench.py); 8 = 6 with the 8-phase K loop
     int ln_fold = 1;                          // fold ln_1 / ln_2 of the fp16 towers into the consuming GEMM where the shape allows
     int xval_fused = 1;                       // cross-validation logits: row argmax fused into the GEMM epilogue (never stored)
     float logit_scale_exp = 100.f;
@@ -713,6 +713,10 @@ int ovmr_debug_gemm(int f32, int variant, const void* A, const void* W, const vo
     if (epi == EPI_LN_BIAS || epi == EPI_LN_BIAS_QGELU) {   // LN-folding epilogues: bias = ln_b fp32 [N], pos = ln_g fp32 [N], res = statistics fp32 [M][K/256][2]
         a.ln_b = (const float*)bias; a.ln_g = (const float*)pos; a.ln_stats = (const float*)res; a.ln_slots = K / 256;
         a.bias = nullptr; a.pos = nullptr; a.res = nullptr;
+    }
+    if (epi == EPI_SCALE_ARGMAX) {                          // fused row argmax: C receives fp32 [M][ceil(N/256)][2] = (max, column bits)
+        a.argmax_out = (float*)C;
+        a.C = nullptr;
     }
     if (epi == EPI_BIAS_RES && pos) {                       // statistics epilogue: pos = fp32 [M][N/256][2] output
         a.stats_out = (float*)pos;
