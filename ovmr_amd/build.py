@@ -1,6 +1,7 @@
 """Build libovmr_hip.so for gfx950 with hipcc (cross-compiles without a GPU).
 
-    python -m ovmr_amd.build            # incremental, parallel per translation unit
+    python -m ovmr_amd.build                 # incremental, parallel per translation unit
+    python -m ovmr_amd.build --experiments   # libovmr_hip_exp.so: + A/B environment switches and timing-only ablation kernels
 The library lands in ovmr_amd/lib/ (git-ignored, but it travels to the GPU box with gpurun).
 """
 from __future__ import annotations
@@ -26,7 +27,15 @@ def _stale(out, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(verbose: bool = True, force: bool = False) -> str:
+def build(verbose: bool = True, force: bool = False, experiments: bool = False) -> str:
+    """experiments=True builds libovmr_hip_exp.so with -DOVMR_EXPERIMENTS: the environment A/B switches and the timing-only
+    ablation kernels tools/gemm_bench.py uses (select it with OVMR_HIP_LIB); the product library has neither."""
+    global OBJ, LIB
+    if experiments:
+        OBJ, LIB = os.path.join(HERE, "lib", "obj_exp"), os.path.join(HERE, "lib", "libovmr_hip_exp.so")
+    else:
+        OBJ, LIB = os.path.join(HERE, "lib", "obj"), os.path.join(HERE, "lib", "libovmr_hip.so")
+    flags = FLAGS + (["-DOVMR_EXPERIMENTS"] if experiments else [])
     os.makedirs(OBJ, exist_ok=True)
     srcs = sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
     hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
@@ -35,7 +44,7 @@ def build(verbose: bool = True, force: bool = False) -> str:
     for f in srcs:
         src, obj = os.path.join(CSRC, f), os.path.join(OBJ, f[:-4] + ".o")
         if force or _stale(obj, [src] + hdrs):
-            jobs.append([HIPCC, *FLAGS, "-c", src, "-o", obj])
+            jobs.append([HIPCC, *flags, "-c", src, "-o", obj])
 
     def run(cmd):
         if verbose:
@@ -54,4 +63,4 @@ def build(verbose: bool = True, force: bool = False) -> str:
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv))
+    print(build(force="--force" in sys.argv, experiments="--experiments" in sys.argv))

@@ -16,6 +16,7 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 
 namespace {
 
@@ -29,7 +30,19 @@ __device__ __forceinline__ half4_t tr_read(const half_t* p) {
     return __builtin_bit_cast(half4_t, r);
 }
 
-template <bool CAUSAL>
+// max over the four lanes {l, l^16, l^32, l^48} that hold one query row's scores, without the LDS crossbar: v_permlane16_swap /
+// v_permlane32_swap exchange 16- / 32-lane halves between two registers, so with both operands = x the two results hold
+// x of this lane and x of the partner lane (ds_bpermute: two ~100-cycle LDS round trips in the max -> exp dependency chain).
+__device__ __forceinline__ float row_max4(float x) {
+    const unsigned u = __builtin_bit_cast(unsigned, x);
+    auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    x = fmaxf(__builtin_bit_cast(float, (unsigned)a[0]), __builtin_bit_cast(float, (unsigned)a[1]));
+    const unsigned w = __builtin_bit_cast(unsigned, x);
+    auto b = __builtin_amdgcn_permlane32_swap(w, w, false, false);
+    return fmaxf(__builtin_bit_cast(float, (unsigned)b[0]), __builtin_bit_cast(float, (unsigned)b[1]));
+}
+
+template <bool CAUSAL, bool SKIP>
 __global__ __launch_bounds__(512, 4) void attn_f16_v1(const half_t* __restrict__ qkv, half_t* __restrict__ out,
                                                    int L, int Lq, int H, int nT, int nWG, int nBH, float scale_log2e) {
     __shared__ __attribute__((aligned(16))) half_t smem[2 * 2 * KB1 * 64];   // [buf][K|V][64 keys][64 d]
@@ -95,8 +108,11 @@ __global__ __launch_bounds__(512, 4) void attn_f16_v1(const half_t* __restrict__
     const int last_tile = t1 - 1;
     const int kmax = CAUSAL ? min(L, (last_tile + 1) * 16) : L;
     const int nb = (kmax + KB1 - 1) / KB1;
+    // (r02) a last key block that holds a single 16-key sub-tile is peeled off the loop (see the tail body below)
+    const bool peel = SKIP && nb > 1 && ((kmax - (nb - 1) * KB1 + 15) >> 4) == 1;
+    const int nb_main = peel ? nb - 1 : nb;
     stage(0, 0);
-    for (int kb = 0; kb < nb; ++kb) {
+    for (int kb = 0; kb < nb_main; ++kb) {
         // every wave must have its own LDS-DMA of block kb retired BEFORE the barrier (hipcc does not always put the
         // vmcnt(0) of __syncthreads() ahead of the barrier: it was found sunk to the first V read, a cross-wave race)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -140,6 +156,11 @@ __global__ __launch_bounds__(512, 4) void attn_f16_v1(const half_t* __restrict__
             }
         }
         half8_t pf[2][2];
+        // FULL = complete key block (3 of 4 at L = 197): straight-line code, no sub-tile tests.  Otherwise (r02) the 16-key
+        // sub-tiles past the last valid key are skipped by the maximum / exponential passes too (wave-uniform branches, P = 0):
+        // before, the last block cost a full softmax pass for 5 valid keys -- a quarter of this kernel's vector instructions.
+        auto softmax = [&](auto full_c) {
+        constexpr bool FULL = decltype(full_c)::value;
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int q = qrow[u];
@@ -154,22 +175,22 @@ __global__ __launch_bounds__(512, 4) void attn_f16_v1(const half_t* __restrict__
                 const int thr = (on[u] ? (CAUSAL ? min(L, q + 1) : L) : 0) - k0 - fg * 4;
 #pragma unroll
                 for (int nt = 0; nt < 4; ++nt)
-                    if (nt < ntv) {
+                    if (FULL || nt < ntv) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) s[u][nt][r] = (nt * 16 + r < thr) ? s[u][nt][r] : -INFINITY;
                     }
             }
-            // (r02) 16-key sub-tiles past the last valid key (L = 197: 3 of the 4 in the last key block) are skipped by the
-            // maximum / exponential / conversion passes too -- wave-uniform branches; their P is 0.  Before, the last block
-            // cost a full softmax pass for 5 valid keys: a quarter of this kernel's vector instructions.
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt)
-                if (nt < ntv) {
+                if (FULL || nt < ntv) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[u][nt][r]);
                 }
-            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            if (SKIP) mx = row_max4(mx);
+            else {
+                mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            }
             const float mxs = mx * scale_log2e;
             if (__builtin_amdgcn_ballot_w64(mxs > m_run[u] + 8.0f) != 0) {     // wave-uniform: some row needs a new reference
                 const float m_new = fmaxf(m_run[u], mxs);
@@ -182,7 +203,7 @@ __global__ __launch_bounds__(512, 4) void attn_f16_v1(const half_t* __restrict__
             const float m_ref = m_run[u];
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) {
-                if (nt < ntv) {
+                if (FULL || nt < ntv) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
                         s[u][nt][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[u][nt][r], scale_log2e, -m_ref));
@@ -198,6 +219,8 @@ __global__ __launch_bounds__(512, 4) void attn_f16_v1(const half_t* __restrict__
                     pf[u][s2][4 + j] = (half_t)s[u][2 * s2 + 1][j];
                 }
         }
+        };
+        softmax(std::true_type{});
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
             if (s2 >= nsv) continue;
@@ -217,6 +240,59 @@ __global__ __launch_bounds__(512, 4) void attn_f16_v1(const half_t* __restrict__
             for (int u = 0; u < 2; ++u) ol[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ones, pf[u][s2], ol[u], 0, 0, 0);   // row sums
         }
     }
+    if (peel) {
+        const int kb = nb - 1, k0 = kb * KB1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                                   // the tail block landed for all waves
+        const half_t* sK = smem + (kb & 1) * (2 * KB1 * 64);
+        const half_t* sV = sK + KB1 * 64;
+        bool on[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) on[u] = act[u] && !(CAUSAL && k0 > (t0 + 2 * wave + u) * 16 + 15);
+        // (r02) Tail block with a single 16-key sub-tile -- every CLIP ViT has one: L = G*G + 1 leaves 5 (G = 14) or 1 key
+        // behind the last full block.  Its own small body: 4 scores per lane instead of 16, so the maximum / exponential /
+        // conversion passes cost a quarter; before, this block ran the full 64-key softmax for 5 valid keys (a quarter of
+        // the kernel's vector instructions at L = 197).  Keys 16..63 of the block get P = 0; their V rows are finite
+        // (the staging clamps the row index), so they add exact zeros.
+        const float4_t zero4 = {0.f, 0.f, 0.f, 0.f};
+        const half8_t kf0 = *(const half8_t*)(sK + fr * 64 + ((fg ^ (fr & 7)) << 3));
+        const half8_t kf1 = *(const half8_t*)(sK + fr * 64 + (((4 + fg) ^ (fr & 7)) << 3));
+        half8_t pt[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            float4_t s1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf0, qf[u][0], zero4, 0, 0, 0);
+            s1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf1, qf[u][1], s1, 0, 0, 0);
+            const int thr = (on[u] ? (CAUSAL ? min(L, qrow[u] + 1) : L) : 0) - k0 - fg * 4;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s1[r] = (r < thr) ? s1[r] : -INFINITY;
+            const float mx = row_max4(fmaxf(fmaxf(s1[0], s1[1]), fmaxf(s1[2], s1[3])));
+            const float mxs = mx * scale_log2e;
+            if (__builtin_amdgcn_ballot_w64(mxs > m_run[u] + 8.0f) != 0) {
+                const float m_new = fmaxf(m_run[u], mxs);
+                const float alpha = __builtin_amdgcn_exp2f(m_run[u] - m_new);
+                m_run[u] = m_new;
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) o[u][dt] *= alpha;
+                ol[u] *= alpha;
+            }
+            const float m_ref = m_run[u];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s1[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s1[r], scale_log2e, -m_ref));
+            pt[u] = (half8_t){(half_t)s1[0], (half_t)s1[1], (half_t)s1[2], (half_t)s1[3], (half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f};
+        }
+        const int kr = fg * 4 + (fr >> 2);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            const int c = dt * 2 + ((fr & 3) >> 1);
+            const int off = (((c ^ (kr & 7)) << 3) + (fr & 1) * 4);
+            const half4_t v0 = tr_read(sV + kr * 64 + off);
+            const half8_t vf = {v0[0], v0[1], v0[2], v0[3], (half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f};
+#pragma unroll
+            for (int u = 0; u < 2; ++u) o[u][dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pt[u], o[u][dt], 0, 0, 0);
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) ol[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ones, pt[u], ol[u], 0, 0, 0);
+    }
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
         if (act[u] && qrow[u] < Lq) {
@@ -234,16 +310,20 @@ __global__ __launch_bounds__(512, 4) void attn_f16_v1(const half_t* __restrict__
 
 }  // namespace
 
-int launch_attention_f16_v1(const half_t* qkv, half_t* out, int B, int L, int Lq, int H, int causal, hipStream_t s) {
-    static int tpw = 0;                                    // query tiles per workgroup (debug: OVMR_ATTN_TPW)
-    if (!tpw) { const char* e = getenv("OVMR_ATTN_TPW"); tpw = e ? atoi(e) : 8; if (tpw < 2 || tpw > 16) tpw = 8; }   // 8 (4 waves x 2 tiles) measured best: 16 -> 198 us, 8 -> 193 us, 4 -> 321 us at B = 512
+int launch_attention_f16_v1(const half_t* qkv, half_t* out, int B, int L, int Lq, int H, int causal, int skip, hipStream_t s) {
+    int tpw = 8;                                           // query tiles per workgroup: 8 (4 waves x 2 tiles) measured best: 16 -> 198 us, 8 -> 193 us, 4 -> 321 us at B = 512
+#ifdef OVMR_EXPERIMENTS
+    if (const char* e = getenv("OVMR_ATTN_TPW")) { tpw = atoi(e); if (tpw < 2 || tpw > 16) tpw = 8; }
+#endif
     const int nT = (Lq + 15) / 16, nWG = (nT + tpw - 1) / tpw;
     const int per = (nT + nWG - 1) / nWG;                  // most tiles any workgroup gets
     const dim3 block(64 * std::max(4, (per + 1) / 2));      // at least 4 waves: the spare ones only help staging K / V
     const float sl2e = 0.125f * 1.4426950408889634f;
     const int nBH = B * H;
     const dim3 grid((unsigned)((long)((nBH + 7) / 8) * 8 * nWG));
-    if (causal) hipLaunchKernelGGL(attn_f16_v1<true>, grid, block, 0, s, qkv, out, L, Lq, H, nT, nWG, nBH, sl2e);
-    else hipLaunchKernelGGL(attn_f16_v1<false>, grid, block, 0, s, qkv, out, L, Lq, H, nT, nWG, nBH, sl2e);
+    if (causal && skip) hipLaunchKernelGGL((attn_f16_v1<true, true>), grid, block, 0, s, qkv, out, L, Lq, H, nT, nWG, nBH, sl2e);
+    else if (causal) hipLaunchKernelGGL((attn_f16_v1<true, false>), grid, block, 0, s, qkv, out, L, Lq, H, nT, nWG, nBH, sl2e);
+    else if (skip) hipLaunchKernelGGL((attn_f16_v1<false, true>), grid, block, 0, s, qkv, out, L, Lq, H, nT, nWG, nBH, sl2e);
+    else hipLaunchKernelGGL((attn_f16_v1<false, false>), grid, block, 0, s, qkv, out, L, Lq, H, nT, nWG, nBH, sl2e);
     return (int)hipGetLastError();
 }

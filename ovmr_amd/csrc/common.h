@@ -11,6 +11,7 @@ typedef float float4_t __attribute__((ext_vector_type(4)));
 typedef float float2_t __attribute__((ext_vector_type(2)));
 
 #define OVMR_WAVE 64
+#define OVMR_MAX_DEVICES 64
 
 // GEMM epilogues (C = epi(A * W^T)), rounding points follow the reference's fp16 CPU path:
 // every nn.Linear output is rounded to fp16 before the next elementwise op.

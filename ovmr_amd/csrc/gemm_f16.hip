@@ -115,10 +115,12 @@ template <int EPI>
 int launch_t128(const GemmArgs& a, hipStream_t s) {
     const int tiles = ((a.M + 127) / 128) * ((a.N + 127) / 128);
     const size_t lds = 2 * 2 * 128 * BK * sizeof(half_t);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static bool attr_set[OVMR_MAX_DEVICES] = {};      // the attribute is per device (one process may drive several)
+    int dev = 0;
+    HIP_CHECK_RET(hipGetDevice(&dev));
+    if (dev >= 0 && dev < OVMR_MAX_DEVICES && !attr_set[dev]) {
         HIP_CHECK_RET(hipFuncSetAttribute((const void*)gemm_f16_t128<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
+        attr_set[dev] = true;
     }
     hipLaunchKernelGGL(gemm_f16_t128<EPI>, dim3(tiles), dim3(256), lds, s, a);
     return (int)hipGetLastError();
@@ -126,33 +128,26 @@ int launch_t128(const GemmArgs& a, hipStream_t s) {
 
 }  // namespace
 
-int launch_gemm_f16_v2(const GemmArgs& a, int pipe, hipStream_t s);     // gemm_f16_v2.hip (256x256x64 LDS-DMA; pipe: pipelined fragment reads)
-int launch_gemm_f16_v3(const GemmArgs& a, int variant, hipStream_t s);  // gemm_f16_v3.hip (LDS-DMA ring, counted vmcnt)
-int launch_gemm_f16_v5(const GemmArgs& a, int variant, hipStream_t s);
-int launch_gemm_f16_v7(const GemmArgs& a, hipStream_t s);               // gemm_f16_v7.hip (4-slot ring, register double-buffered fragments)  // gemm_f16_v5.hip (L2 prefetch + LDS-staged epilogue)
+int launch_gemm_f16_v5(const GemmArgs& a, int variant, hipStream_t s);  // gemm_f16_v5.hip: 256(128)x256x64 LDS-DMA tiles, fused epilogues
 
+// variant 0: the 128x128 register-staged kernel above for every shape; 6: 256-row tiles with the double-buffered K loop;
+// 8 (default): 6 with the 8-phase ping-pong K loop.  6 / 8 fall back to the 128x128 kernel for shapes they do not take
+// (M < 256, N < 128, ...).  Experiment builds (OVMR_EXPERIMENTS) add timing-only ablation variants (gemm_f16_v5.hip).
 int launch_gemm_f16(const GemmArgs& a, int variant, hipStream_t s) {
     if (a.M <= 0 || a.N <= 0) return 0;
     if (a.K <= 0 || (a.K % BK) != 0 || (a.lda & 7) || (a.ldw & 7)) return -2;  // caller pads K to 64
-    const bool v5_variant = (variant >= 5 && variant <= 8) || variant == 18 || variant == 19 || variant == 28 || variant == 29;
+    const int v5 = variant == 0 ? 8 : variant;
     if (a.epi == EPI_SCALE_ARGMAX) {                                            // only the v5 kernel; -4: shape not supported
-        const int rc = launch_gemm_f16_v5(a, v5_variant ? variant : 6, s);
+        const int rc = launch_gemm_f16_v5(a, v5, s);
         return rc == -100 ? -4 : rc;
     }
     if (a.epi == EPI_LN_BIAS || a.epi == EPI_LN_BIAS_QGELU || a.stats_out) {   // only the v5 kernel folds LayerNorm
-        const int rc = launch_gemm_f16_v5(a, v5_variant ? variant : 6, s);
+        const int rc = launch_gemm_f16_v5(a, v5, s);
         return rc == -100 ? -4 : rc;
     }
     if (variant >= 1) {
-        int rc;
-        if (v5_variant) rc = launch_gemm_f16_v5(a, variant, s);
-        else if (variant == 11) rc = launch_gemm_f16_v7(a, s);
-        else if (variant == 1) rc = launch_gemm_f16_v2(a, 0, s);
-        else if (variant == 4) rc = launch_gemm_f16_v2(a, 1, s);
-        else if (variant == 12 || variant == 13) rc = launch_gemm_f16_v2(a, variant - 10, s);   // timing-only ablations
-        else if (variant == 2 || variant == 3) rc = launch_gemm_f16_v3(a, variant, s);
-        else return -5;                                                                           // unknown variant
-        if (rc != -100) return rc;   // -100: shape not supported -> fall through to t128
+        const int rc = launch_gemm_f16_v5(a, variant, s);
+        if (rc != -100) return rc;   // -100: shape not supported -> the 128x128 kernel
     }
     switch (a.epi) {
         case EPI_NONE: return launch_t128<EPI_NONE>(a, s);

@@ -1,5 +1,8 @@
-// fp16 MFMA GEMM, variant 6 (the default): 256(128)x256x64 tiles, both operands streamed into a double-buffered LDS stage by
-// LDS-DMA (global_load_lds, 16 B per lane, XOR-swizzled 128-byte rows), 8 waves as 2 x 4, software-pipelined fragment reads.
+// fp16 MFMA GEMM, variants 6 and 8 (the default): 256(128)x256x64 tiles, both operands streamed into LDS by LDS-DMA
+// (global_load_lds, 16 B per lane, XOR-swizzled 128-byte rows), 8 waves as 2 x 4.  K loops: variant 8 = the 8-phase ping-pong
+// loop (four half-tiles per K-tile, counted vmcnt, the two wave rows one barrier apart: see OPT & 16 below; r02: qkv 369 -> 324,
+// c_fc 522 -> 479, c_proj 462 -> 390, out_proj 149 -> 133 us at batch 512); variant 6 = double buffer with a drain per K-tile
+// and software-pipelined fragment reads (also the fallback of 8 for an odd number of K-tiles and for 128-row tiles).
 //
 // Epilogue (measured with tools/gemm_bench.py variants 6 / 18 / 19, profiles/r01g_gemm_epilogue.md: with K = 768 the
 // epilogue was 24-44 % of the kernel, the K loop alone runs at 1.1-1.2 PFLOP/s):
@@ -29,6 +32,14 @@
 
 namespace {
 
+// A/B switches of tools/gemm_bench.py exist only in experiment builds (python -m ovmr_amd.build --experiments ->
+// libovmr_hip_exp.so); the product library reads no environment variable and carries no timing-only kernel.
+#ifdef OVMR_EXPERIMENTS
+inline int exp_env(const char* name) { const char* e = getenv(name); return e ? atoi(e) : 0; }
+#else
+inline int exp_env(const char*) { return 0; }
+#endif
+
 constexpr int BK5 = 64, BN5 = 256;
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
@@ -38,9 +49,9 @@ __device__ __forceinline__ float dpp_f32(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
 }
 
-// OPT bits: 1 / 2 nontemporal LDS-DMA for the A / W operand, 4 K loop with the iteration boundary inside the MFMA stream (8: six
-// instead of two deferred steps), 64 NOSTORE / 128 NOEPI (timing-only ablations, variants
-// 18 / 19), 512 NT (nontemporal C stores)
+// OPT bits: 1 / 2 nontemporal LDS-DMA for the A / W operand, 4 K loop with the iteration boundary inside the MFMA stream,
+// 16 the 8-phase ping-pong K loop (256-row tiles), 64 NOSTORE / 128 NOEPI (timing-only ablations, experiment builds only),
+// 512 NT (nontemporal C stores)
 template <int EPI, int MT, int OPT>
 __global__ __launch_bounds__(512) void gemm_f16_v5_kernel(GemmArgs a, int tiles_m, int tiles_n) {
     constexpr int BM = MT * 32;
@@ -347,7 +358,7 @@ __global__ __launch_bounds__(512) void gemm_f16_v5_kernel(GemmArgs a, int tiles_
     // before its last MFMAs, so the wait for the next tile's LDS-DMA, the workgroup barrier, the next tile's first six fragment
     // reads and the LDS-DMA issue for the tile after it all happen in front of the last two steps (8 MFMAs per wave): the matrix
     // pipe works through those while the new fragments are in flight, instead of every wave of the CU waiting on LDS at once.
-    constexpr int D = ((OPT & 8) && MT == 8) ? 6 : 2, R = D + 2;   // deferred steps (<= MT: they must all use fb[1]) / A-fragment ring
+    constexpr int D = 2, R = D + 2;                 // deferred steps / A-fragment ring
     static_assert((2 * MT) % R == 0 && D <= MT, "");
     half8_t fb[2][4], fa[R];
     auto first_reads = [&](const char* buf) {
@@ -674,10 +685,12 @@ template <int EPI, int MT, int OPT>
 int launch_v5_k(const GemmArgs& b, int tiles_m, int tiles_n, hipStream_t s) {
     constexpr int BM = MT * 32;
     const size_t lds = (size_t)2 * (BM + BN5) * 128 + 2 * BN5 * 4 + 2 * BM * 4;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static bool attr_set[OVMR_MAX_DEVICES] = {};      // the attribute is per device (one process may drive several)
+    int dev = 0;
+    HIP_CHECK_RET(hipGetDevice(&dev));
+    if (dev >= 0 && dev < OVMR_MAX_DEVICES && !attr_set[dev]) {
         HIP_CHECK_RET(hipFuncSetAttribute((const void*)gemm_f16_v5_kernel<EPI, MT, OPT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
+        attr_set[dev] = true;
     }
     hipLaunchKernelGGL((gemm_f16_v5_kernel<EPI, MT, OPT>), dim3(tiles_m * tiles_n), dim3(512), lds, s, b, tiles_m, tiles_n);
     return (int)hipGetLastError();
@@ -689,8 +702,7 @@ int launch_v5(const GemmArgs& a, hipStream_t s) {
     const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + BN5 - 1) / BN5;
     GemmArgs b = a;
     if (b.n_group <= 0) {
-        static int force = -1;
-        if (force < 0) { const char* e = getenv("OVMR_N_GROUP"); force = e ? atoi(e) : 0; }
+        static const int force = exp_env("OVMR_N_GROUP");
         // measured (profiles/r01e_gemm_experiments.md): groups of 4-6 raise the L2 hit rate of qkv / c_fc from 65-68 %
         // to 72-73 % but move the run time by < 2 %, and hurt c_proj; the default therefore stays row-major (G = all)
         // with the 8-phase K loop (r02c, same-process A/B at batch 512): groups of 4 N tiles take 1.5-2.5 % off qkv / c_fc
@@ -703,8 +715,7 @@ int launch_v5(const GemmArgs& a, hipStream_t s) {
         // slower) nor for small outputs the next kernel reads straight back (logits for the argmax).  The hint has to be
         // a template parameter: a run-time branch around two stores of the same value is merged by the compiler, which
         // drops the hint.
-        static int force = -1;
-        if (force < 0) { const char* e = getenv("OVMR_NT_STORE"); force = e ? atoi(e) : 0; }
+        static const int force = exp_env("OVMR_NT_STORE");
         b.nt_store = force ? force : (b.epi != EPI_BIAS_RES && (size_t)b.M * b.N * 2 >= ((size_t)48 << 20) ? 2 : 1);
     }
     constexpr int P8 = OPT & 16;                        // 8-phase ping-pong K loop (256-row tiles; it replaces the OPT & 4 loop there)
@@ -713,20 +724,20 @@ int launch_v5(const GemmArgs& a, hipStream_t s) {
     if constexpr (PLAIN && OV_OK && (EPI == EPI_LN_BIAS || EPI == EPI_LN_BIAS_QGELU)) {
         // the LayerNorm-folding launches also run the K loop with the boundary inside the MFMA stream (qkv_ln 354 -> 343 us,
         // c_fc_ln 525 -> 518 us; the plain bias / QuickGELU launches of the same shapes do not gain)
-        static int ov_force = -1;
-        if (ov_force < 0) { const char* e = getenv("OVMR_K_OVERLAP"); ov_force = e ? atoi(e) : 0; }
+        static const int ov_force = exp_env("OVMR_K_OVERLAP");
         if (ov_force != 1) {
             if (b.nt_store == 2) return launch_v5_k<EPI, MT, 4 | 512>(b, tiles_m, tiles_n, s);
             return launch_v5_k<EPI, MT, 4>(b, tiles_m, tiles_n, s);
         }
     }
     if constexpr (PLAIN && EPI != EPI_BIAS_RES) {
-        static int a_nt_all = -1;                       // experiment: OVMR_A_NT=3 -> nontemporal A stream on every epilogue
-        if (a_nt_all < 0) { const char* e = getenv("OVMR_A_NT"); a_nt_all = e && atoi(e) == 3; }
+#ifdef OVMR_EXPERIMENTS
+        static const bool a_nt_all = exp_env("OVMR_A_NT") == 3;   // nontemporal A stream on every epilogue: measured slower (r02c)
         if (a_nt_all) {
             if (b.nt_store == 2) return launch_v5_k<EPI, MT, P8 | 1 | 512>(b, tiles_m, tiles_n, s);
             return launch_v5_k<EPI, MT, P8 | 1>(b, tiles_m, tiles_n, s);
         }
+#endif
         if (b.nt_store == 2) return launch_v5_k<EPI, MT, P8 | 512>(b, tiles_m, tiles_n, s);
     }
     if constexpr (PLAIN && EPI == EPI_BIAS_RES) {
@@ -736,9 +747,7 @@ int launch_v5(const GemmArgs& a, hipStream_t s) {
         //     9-12 N tiles per A panel the same hint costs 6-11 %, and on the W operand it always costs.
         // (2) K >= 2048: the K loop with the iteration boundary inside the MFMA stream (OPT & 4): c_proj 467 -> 449 us; at
         //     K = 768 (12 K-tiles) it is neutral to 2 % slower.
-        static int a_nt_force = -1, ov_force = -1;
-        if (a_nt_force < 0) { const char* e = getenv("OVMR_A_NT"); a_nt_force = e ? atoi(e) : 0; }       // 1 = never, 2 = always
-        if (ov_force < 0) { const char* e = getenv("OVMR_K_OVERLAP"); ov_force = e ? atoi(e) : 0; }      // 1 = never, 2 = always
+        static const int a_nt_force = exp_env("OVMR_A_NT"), ov_force = exp_env("OVMR_K_OVERLAP");   // 1 = never, 2 = always
         const bool a_nt = a_nt_force != 1 && (a_nt_force == 2 || (tiles_n <= 4 && tiles_m * tiles_n >= 512));
         const bool ov = OV_OK && ov_force != 1 && (ov_force == 2 || b.K >= 2048);
         if (a_nt && ov) return launch_v5_k<EPI, MT, 5>(b, tiles_m, tiles_n, s);
@@ -748,14 +757,9 @@ int launch_v5(const GemmArgs& a, hipStream_t s) {
     return launch_v5_k<EPI, MT, OPT>(b, tiles_m, tiles_n, s);
 }
 
-int g_force_mt = -1;   // debug: OVMR_FORCE_MT=4|8 pins the M tile (tools/gemm_bench.py)
-
 template <int EPI, int OPT>
 int pick_v5(const GemmArgs& a, hipStream_t s) {
-    if (g_force_mt < 0) {
-        const char* e = getenv("OVMR_FORCE_MT");
-        g_force_mt = e ? atoi(e) : 0;
-    }
+    static const int g_force_mt = exp_env("OVMR_FORCE_MT");   // experiment builds: 4 | 8 pins the M tile
     auto eff = [&](int bm) {
         const double t = (double)((a.M + bm - 1) / bm) * ((a.N + BN5 - 1) / BN5);
         return t / (ceil(t / 256.0) * 256.0);
@@ -785,7 +789,8 @@ int dispatch_v5(const GemmArgs& a, hipStream_t s) {
 
 }  // namespace
 
-// variant 6: the default; 18 / 19: timing-only epilogue ablations (no global stores / no epilogue at all)
+// variant 8: the default (8-phase K loop); 6: the double-buffered K loop (also what 8 runs for an odd number of K-tiles and
+// for 128-row tiles)
 int launch_gemm_f16_v5(const GemmArgs& a, int variant, hipStream_t s) {
     if (a.epi == EPI_SCALE_ARGMAX) {
         if (a.M < 256 || a.N < 128 || !a.argmax_out || (long)a.M * a.lda * 2 >= 0x7fffffffL || (long)a.N * a.ldw * 2 >= 0x7fffffffL)
@@ -799,11 +804,14 @@ int launch_gemm_f16_v5(const GemmArgs& a, int variant, hipStream_t s) {
     if (lnf && ((a.N & 63) || !a.ln_stats || a.ln_slots < 1 || !a.ln_g || !a.ln_b)) return -2;
     if (a.stats_out && (a.epi != EPI_BIAS_RES || (a.N & 255))) return -2;
     switch (variant) {
+#ifdef OVMR_EXPERIMENTS   // timing-only ablations (their outputs are wrong by construction): no stores / no epilogue at all
         case 18: return a.epi == EPI_BIAS_QGELU ? pick_v5<EPI_BIAS_QGELU, 64>(a, s) : pick_v5<EPI_BIAS, 64>(a, s);
         case 19: return pick_v5<EPI_BIAS, 128>(a, s);
+        case 28: return a.epi == EPI_BIAS_QGELU ? pick_v5<EPI_BIAS_QGELU, 16 | 64>(a, s) : pick_v5<EPI_BIAS, 16 | 64>(a, s);
+        case 29: return pick_v5<EPI_BIAS, 16 | 128>(a, s);
+#endif
+        case 6: return dispatch_v5<0>(a, s);
         case 8: return (a.K % 128) == 0 ? dispatch_v5<16>(a, s) : dispatch_v5<0>(a, s);   // 8-phase K loop: two K-tiles per iteration
-        case 28: return a.epi == EPI_BIAS_QGELU ? pick_v5<EPI_BIAS_QGELU, 16 | 64>(a, s) : pick_v5<EPI_BIAS, 16 | 64>(a, s);   // timing-only: no stores
-        case 29: return pick_v5<EPI_BIAS, 16 | 128>(a, s);                                                                      // timing-only: no epilogue
-        default: return dispatch_v5<0>(a, s);
+        default: return -5;                                                                // unknown variant
     }
 }

@@ -701,6 +701,7 @@ int ovmr_debug_gemm(int f32, int variant, const void* A, const void* W, const vo
                     const void* pos, void* C, int M, int N, int K, int ldc, int epi, float scale,
                     int rows_in, int rows_out, ovmr_stream stream) {
     GemmArgs a = gemm(A, K, W, K, C, ldc, M, N, K, epi, bias, res, ldc);
+#ifdef OVMR_EXPERIMENTS
     if (const char* e = getenv("OVMR_DEBUG_LDPAD")) {   // stride experiment (tools/gemm_bench.py --ldpad): operands have padded rows
         a.lda = K + atoi(e);
         a.ldw = K + atoi(e);
@@ -709,6 +710,7 @@ int ovmr_debug_gemm(int f32, int variant, const void* A, const void* W, const vo
         a.a_blocked = atoi(e) & 1;
         a.w_blocked = (atoi(e) >> 1) & 1;
     }
+#endif
     a.pos = pos; a.scale = scale; a.rows_in = rows_in; a.rows_out = rows_out;
     if (epi == EPI_LN_BIAS || epi == EPI_LN_BIAS_QGELU) {   // LN-folding epilogues: bias = ln_b fp32 [N], pos = ln_g fp32 [N], res = statistics fp32 [M][K/256][2]
         a.ln_b = (const float*)bias; a.ln_g = (const float*)pos; a.ln_stats = (const float*)res; a.ln_slots = K / 256;

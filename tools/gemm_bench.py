@@ -10,7 +10,13 @@ import json
 import os
 import sys
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+# the A/B environment switches and the timing-only ablation variants (18 / 19 / 28 / 29) live in the experiment build only:
+#   python -m ovmr_amd.build --experiments
+_exp = os.path.join(ROOT, "ovmr_amd", "lib", "libovmr_hip_exp.so")
+if os.path.exists(_exp):
+    os.environ.setdefault("OVMR_HIP_LIB", _exp)
 import torch
 from ovmr_amd import runtime
 
