@@ -764,10 +764,21 @@ int pick_v5(const GemmArgs& a, hipStream_t s) {
         const double t = (double)((a.M + bm - 1) / bm) * ((a.N + BN5 - 1) / BN5);
         return t / (ceil(t / 256.0) * 256.0);
     };
-    // grids far below one round of CUs (the CLS-only tail of the last vision block: 512 rows): the smaller tile doubles the
-    // workgroups and shortens each K-tile (out_proj 22.5 -> 14.0 us, c_proj 67.7 -> 42.6 us at 512 rows)
     const double t256 = (double)((a.M + 255) / 256) * ((a.N + BN5 - 1) / BN5);
-    const bool big = g_force_mt ? g_force_mt == 8 : (t256 >= 64 && eff(256) + 0.08 >= eff(128));
+    bool big;
+    if (g_force_mt) big = g_force_mt == 8;
+    else if ((OPT & 16) && (a.K % 128) == 0) {
+        // 8-phase K loop on 256-row tiles against the double-buffered loop on 128-row tiles: a round of 128-row tiles takes
+        // ~0.74 of a round of 256-row tiles (r02d, batch 256: out_proj 19.8 vs 26.6 us, c_proj 59 vs 78 us per round), so the
+        // big tile wins unless the small one saves a whole round -- e.g. 591 tiles (batch 256, N = 768): 3 rounds against
+        // 5 x 0.74; the CLS-only tail (6 tiles) stays on 128-row tiles.
+        const double t128 = (double)((a.M + 127) / 128) * ((a.N + BN5 - 1) / BN5);
+        big = ceil(t256 / 256.0) <= 0.74 * ceil(t128 / 256.0);
+    } else {
+        // grids far below one round of CUs (the CLS-only tail of the last vision block: 512 rows): the smaller tile doubles the
+        // workgroups and shortens each K-tile (out_proj 22.5 -> 14.0 us, c_proj 67.7 -> 42.6 us at 512 rows)
+        big = t256 >= 64 && eff(256) + 0.08 >= eff(128);
+    }
     return big ? launch_v5<EPI, 8, OPT>(a, s) : launch_v5<EPI, 4, OPT>(a, s);
 }
 
