@@ -45,7 +45,7 @@ def parse():
     ap.add_argument("--query-batch", type=int, default=256, help="query images per inference call (256 = BASELINE config 3)")
     ap.add_argument("--classes-per-batch", type=int, default=256)
     ap.add_argument("--gemm", type=int, default=int(os.environ.get("OVMR_GEMM", "8")))
-    ap.add_argument("--attn", type=int, default=int(os.environ.get("OVMR_ATTN", "1")))
+    ap.add_argument("--attn", type=int, default=int(os.environ.get("OVMR_ATTN", "3")))
     ap.add_argument("--ln-fold", type=int, default=int(os.environ.get("OVMR_LN_FOLD", "1")),
                     help="1: ln_1/ln_2 folded into the consuming GEMM epilogue; 0: separate LayerNorm kernels")
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -195,6 +195,8 @@ __global__ __launch_bounds__(128) void attn_f32_small(const float* __restrict__ 
 
 int launch_attention_f16_v1(const half_t* qkv, half_t* out, int B, int L, int Lq, int H, int causal, int skip, hipStream_t s);  // attention_v1.hip
 
+int launch_attention_f16_v3(const half_t* qkv, half_t* out, int B, int L, int Lq, int H, int causal, hipStream_t s);  // attention_v3.hip
+
 int launch_attention_f16(const half_t* qkv, half_t* out, int B, int L, int H, int causal, int variant, hipStream_t s) {
     return launch_attention_f16_q(qkv, out, B, L, L, H, causal, variant, s);
 }
@@ -202,6 +204,11 @@ int launch_attention_f16(const half_t* qkv, half_t* out, int B, int L, int H, in
 int launch_attention_f16_q(const half_t* qkv, half_t* out, int B, int L, int Lq, int H, int causal, int variant, hipStream_t s) {
     if (B <= 0 || L <= 0 || Lq <= 0) return 0;
     if (Lq > L) return -2;
+    if (variant == 3) {               // single-pass kernel for the ViT-B/16 image shape; everything else as variant 1
+        const int rc = launch_attention_f16_v3(qkv, out, B, L, Lq, H, causal, s);
+        if (rc != -100) return rc;
+        variant = 1;
+    }
     if ((variant == 1 || variant == 2) && L >= 128) {   // short (text) sequences: one key block, the plain kernel is faster (tools/attn_bench.py)
         int rc = launch_attention_f16_v1(qkv, out, B, L, Lq, H, causal, variant == 1, s);   // 2: A/B arm without the sub-tile skipping
         if (rc != -100) return rc;

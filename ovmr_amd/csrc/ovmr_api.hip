@@ -40,7 +40,7 @@ struct ovmr_handle {
     std::vector<void*> derived;   // layouts rebuilt by every ovmr_finalize
     std::string err;
     bool finalized = false;
-    int gemm_variant = 8, attn_variant = 1;   // defaults = fastest verified kernels (tools/gemm_bench.py); 8 = 6 with the 8-phase K loop
+    int gemm_variant = 8, attn_variant = 3;   // defaults = fastest verified kernels (tools/gemm_bench.py, tools/attn_bench.py); attention 3 falls back to 1 / 0 by shape
     int ln_fold = 1;                          // fold ln_1 / ln_2 of the fp16 towers into the consuming GEMM where the shape allows
     int xval_fused = 1;                       // cross-validation logits: row argmax fused into the GEMM epilogue (never stored)
     float logit_scale_exp = 100.f;

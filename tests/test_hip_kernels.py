@@ -11,7 +11,7 @@ pytestmark = pytest.mark.gpu
 
 EPI_NONE, EPI_BIAS, EPI_BIAS_QGELU, EPI_BIAS_RES, EPI_PATCH, EPI_SCALE = range(6)
 GEMM_VARIANTS = [0, 6, 8]       # 0: 128x128 register-staged; 6 / 8: 256-row LDS-DMA tiles (double-buffered / 8-phase K loop)
-ATTN_VARIANTS = [0, 1, 2]
+ATTN_VARIANTS = [0, 1, 2, 3]
 
 
 @pytest.fixture(scope="module")
@@ -149,7 +149,8 @@ def _ref_attention(qkv, B, L, H, causal):
 
 @pytest.mark.parametrize("variant", ATTN_VARIANTS)
 @pytest.mark.parametrize("B,L,H,causal", [(3, 197, 12, 0), (2, 5, 2, 0), (4, 77, 8, 1), (5, 9, 2, 1), (1, 577, 16, 0),
-                                          (2, 64, 4, 0), (2, 65, 4, 1), (3, 6, 8, 1)])
+                                          (2, 64, 4, 0), (2, 65, 4, 1), (3, 6, 8, 1), (2, 193, 3, 0), (2, 208, 2, 0), (1, 200, 4, 0),
+                                          (2, 192, 2, 0), (2, 209, 2, 0)])     # 193..208: the single-pass kernel (variant 3)
 def test_attention_f16(lib, variant, B, L, H, causal):
     g = torch.Generator().manual_seed(B * L + H)
     qkv = (torch.randn(B * L, 3 * H * 64, generator=g)).half()
