@@ -62,9 +62,15 @@ void ovmr_destroy(ovmr_handle* h);
 const char* ovmr_last_error(const ovmr_handle* h);
 const char* ovmr_version(void);
 
-/* Kernel-variant switch used by tests/bench to A/B implementations: key in {"gemm","attn","ln_fold"}.
+/* Kernel-variant switch used by tests/bench to A/B implementations: key in {"gemm","attn","ln_fold","xval_fused"}.
+ * "gemm" (default 8): 8 = 256-row LDS-DMA tiles with the 8-phase ping-pong K loop, 6 = the same tiles with the double-buffered
+ *   K loop, 0 = the 128x128 register-staged kernel everywhere (LayerNorm-folding and fused-argmax launches still take the tile kernel).
+ * "attn" (default 3): 3 = single-pass persistent kernel where the shape is its own (non-causal, 192 < L <= 208), else as 1;
+ *   1 = flash-style LDS-DMA kernel for L >= 128, else as 0; 0 = the plain flash-style kernel.
  * "ln_fold" (default 1): ln_1 / ln_2 of the fp16 towers are folded into the consuming GEMM where the shape allows
- * (width % 256 == 0 and >= 256 token rows); 0 runs the separate LayerNorm kernel everywhere. */
+ *   (width % 256 == 0 and >= 256 token rows); 0 runs the separate LayerNorm kernel everywhere.
+ * "xval_fused" (default 1): ovmr_xval_counts takes the row argmax inside the logits GEMM's epilogue (the [R, C] logits are never
+ *   written); 0 materialises fp16 logits in workspace chunks and runs a row-argmax kernel on them.  Identical counters. */
 int ovmr_set_option(ovmr_handle* h, const char* key, int value);
 
 /* Weight ingestion -- replaces build_model()/convert_weights()/load_state_dict
@@ -156,7 +162,8 @@ double ovmr_flops_per_prompt(const ovmr_handle* h, int seq_len);
  * `variant` selects the kernel implementation as ovmr_set_option does; `epi` is the epilogue id of
  * ovmr_amd/csrc/common.h.  A [M,K], W [N,K], C [M,ldc]; qkv [B*L, 3*H*64] -> out [B*L, H*64].
  * For the LayerNorm-folding epilogues (epi 6/7) ovmr_debug_gemm reads `bias` as the folded bias fp32 [N], `pos` as the
- * column sums fp32 [N] and `res` as the row statistics fp32 [M][K/256][2]; with epi 3 a non-NULL `pos` receives the
+ * column sums fp32 [N] and `res` as the row statistics fp32 [M][K/256][2]; with epi 8 (fused row argmax) C receives
+ * fp32 [M][ceil(N/256)][2] = (tile maximum, bits of the lowest column holding it); with epi 3 a non-NULL `pos` receives the
  * statistics of the stored rows, fp32 [M][N/256][2]. */
 int ovmr_debug_gemm(int f32, int variant, const void* A, const void* W, const void* bias, const void* res,
                     const void* pos, void* C, int M, int N, int K, int ldc, int epi, float scale,

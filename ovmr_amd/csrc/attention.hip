@@ -193,7 +193,7 @@ __global__ __launch_bounds__(128) void attn_f32_small(const float* __restrict__ 
 
 }  // namespace
 
-int launch_attention_f16_v1(const half_t* qkv, half_t* out, int B, int L, int Lq, int H, int causal, int skip, hipStream_t s);  // attention_v1.hip
+int launch_attention_f16_v1(const half_t* qkv, half_t* out, int B, int L, int Lq, int H, int causal, hipStream_t s);  // attention_v1.hip
 
 int launch_attention_f16_v3(const half_t* qkv, half_t* out, int B, int L, int Lq, int H, int causal, hipStream_t s);  // attention_v3.hip
 
@@ -209,8 +209,8 @@ int launch_attention_f16_q(const half_t* qkv, half_t* out, int B, int L, int Lq,
         if (rc != -100) return rc;
         variant = 1;
     }
-    if ((variant == 1 || variant == 2) && L >= 128) {   // short (text) sequences: one key block, the plain kernel is faster (tools/attn_bench.py)
-        int rc = launch_attention_f16_v1(qkv, out, B, L, Lq, H, causal, variant == 1, s);   // 2: A/B arm without the sub-tile skipping
+    if (variant == 1 && L >= 128) {   // short (text) sequences: one key block, the plain kernel is faster (tools/attn_bench.py)
+        int rc = launch_attention_f16_v1(qkv, out, B, L, Lq, H, causal, s);
         if (rc != -100) return rc;
     }
     const int nT = (Lq + 15) / 16, nWG = (nT + 3) / 4;

@@ -9,6 +9,10 @@
 //     threshold-form masking (183 -> 167 us);
 //     a variant with a specialised body for complete unmasked key blocks spilled registers at the 128-VGPR cap and ran
 //     at 255 us -- not kept;
+//   * (r02) a tail key block that holds a single 16-key sub-tile (every CLIP ViT has one: L = G*G + 1) is peeled off the block
+//     loop into its own small body (4 scores per lane instead of 16), and the row maximum crosses lanes with
+//     v_permlane16_swap / v_permlane32_swap instead of two LDS round trips: 170 -> 162 us at 512 x 12 x 197 (same box);
+//     the ViT-B/16 image shape itself now runs attention_v3.hip (142 us);
 //   * two 16-row query tiles per wave, 4 waves (8 tiles) per workgroup, both tiles of a wave sharing every K / V fragment
 //     read from LDS; <= 128 VGPRs, i.e. 4 waves per SIMD (3 waves/SIMD: 233 us instead of 193 at B = 512); the workgroups
 //     of a head run on one XCD; 16 tiles / 7 waves per workgroup (K/V read once) measured 198 us, 4 tiles 321 us.
@@ -16,7 +20,6 @@
 
 #include <algorithm>
 #include <cstdlib>
-#include <type_traits>
 
 namespace {
 
@@ -42,7 +45,7 @@ __device__ __forceinline__ float row_max4(float x) {
     return fmaxf(__builtin_bit_cast(float, (unsigned)b[0]), __builtin_bit_cast(float, (unsigned)b[1]));
 }
 
-template <bool CAUSAL, bool SKIP>
+template <bool CAUSAL>
 __global__ __launch_bounds__(512, 4) void attn_f16_v1(const half_t* __restrict__ qkv, half_t* __restrict__ out,
                                                    int L, int Lq, int H, int nT, int nWG, int nBH, float scale_log2e) {
     __shared__ __attribute__((aligned(16))) half_t smem[2 * 2 * KB1 * 64];   // [buf][K|V][64 keys][64 d]
@@ -109,7 +112,7 @@ __global__ __launch_bounds__(512, 4) void attn_f16_v1(const half_t* __restrict__
     const int kmax = CAUSAL ? min(L, (last_tile + 1) * 16) : L;
     const int nb = (kmax + KB1 - 1) / KB1;
     // (r02) a last key block that holds a single 16-key sub-tile is peeled off the loop (see the tail body below)
-    const bool peel = SKIP && nb > 1 && ((kmax - (nb - 1) * KB1 + 15) >> 4) == 1;
+    const bool peel = nb > 1 && ((kmax - (nb - 1) * KB1 + 15) >> 4) == 1;
     const int nb_main = peel ? nb - 1 : nb;
     stage(0, 0);
     for (int kb = 0; kb < nb_main; ++kb) {
@@ -156,11 +159,6 @@ __global__ __launch_bounds__(512, 4) void attn_f16_v1(const half_t* __restrict__
             }
         }
         half8_t pf[2][2];
-        // FULL = complete key block (3 of 4 at L = 197): straight-line code, no sub-tile tests.  Otherwise (r02) the 16-key
-        // sub-tiles past the last valid key are skipped by the maximum / exponential passes too (wave-uniform branches, P = 0):
-        // before, the last block cost a full softmax pass for 5 valid keys -- a quarter of this kernel's vector instructions.
-        auto softmax = [&](auto full_c) {
-        constexpr bool FULL = decltype(full_c)::value;
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int q = qrow[u];
@@ -175,22 +173,14 @@ __global__ __launch_bounds__(512, 4) void attn_f16_v1(const half_t* __restrict__
                 const int thr = (on[u] ? (CAUSAL ? min(L, q + 1) : L) : 0) - k0 - fg * 4;
 #pragma unroll
                 for (int nt = 0; nt < 4; ++nt)
-                    if (FULL || nt < ntv) {
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) s[u][nt][r] = (nt * 16 + r < thr) ? s[u][nt][r] : -INFINITY;
-                    }
+                    for (int r = 0; r < 4; ++r) s[u][nt][r] = (nt * 16 + r < thr) ? s[u][nt][r] : -INFINITY;
             }
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt)
-                if (FULL || nt < ntv) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[u][nt][r]);
-                }
-            if (SKIP) mx = row_max4(mx);
-            else {
-                mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            }
+                for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[u][nt][r]);
+            mx = row_max4(mx);
             const float mxs = mx * scale_log2e;
             if (__builtin_amdgcn_ballot_w64(mxs > m_run[u] + 8.0f) != 0) {     // wave-uniform: some row needs a new reference
                 const float m_new = fmaxf(m_run[u], mxs);
@@ -202,15 +192,10 @@ __global__ __launch_bounds__(512, 4) void attn_f16_v1(const half_t* __restrict__
             }
             const float m_ref = m_run[u];
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt) {
-                if (FULL || nt < ntv) {
+            for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        s[u][nt][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[u][nt][r], scale_log2e, -m_ref));
-                } else {
-                    s[u][nt] = zero;
-                }
-            }
+                for (int r = 0; r < 4; ++r)
+                    s[u][nt][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[u][nt][r], scale_log2e, -m_ref));
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
@@ -219,8 +204,6 @@ __global__ __launch_bounds__(512, 4) void attn_f16_v1(const half_t* __restrict__
                     pf[u][s2][4 + j] = (half_t)s[u][2 * s2 + 1][j];
                 }
         }
-        };
-        softmax(std::true_type{});
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
             if (s2 >= nsv) continue;
@@ -310,7 +293,7 @@ __global__ __launch_bounds__(512, 4) void attn_f16_v1(const half_t* __restrict__
 
 }  // namespace
 
-int launch_attention_f16_v1(const half_t* qkv, half_t* out, int B, int L, int Lq, int H, int causal, int skip, hipStream_t s) {
+int launch_attention_f16_v1(const half_t* qkv, half_t* out, int B, int L, int Lq, int H, int causal, hipStream_t s) {
     int tpw = 8;                                           // query tiles per workgroup: 8 (4 waves x 2 tiles) measured best: 16 -> 198 us, 8 -> 193 us, 4 -> 321 us at B = 512
 #ifdef OVMR_EXPERIMENTS
     if (const char* e = getenv("OVMR_ATTN_TPW")) { tpw = atoi(e); if (tpw < 2 || tpw > 16) tpw = 8; }
@@ -321,9 +304,7 @@ int launch_attention_f16_v1(const half_t* qkv, half_t* out, int B, int L, int Lq
     const float sl2e = 0.125f * 1.4426950408889634f;
     const int nBH = B * H;
     const dim3 grid((unsigned)((long)((nBH + 7) / 8) * 8 * nWG));
-    if (causal && skip) hipLaunchKernelGGL((attn_f16_v1<true, true>), grid, block, 0, s, qkv, out, L, Lq, H, nT, nWG, nBH, sl2e);
-    else if (causal) hipLaunchKernelGGL((attn_f16_v1<true, false>), grid, block, 0, s, qkv, out, L, Lq, H, nT, nWG, nBH, sl2e);
-    else if (skip) hipLaunchKernelGGL((attn_f16_v1<false, true>), grid, block, 0, s, qkv, out, L, Lq, H, nT, nWG, nBH, sl2e);
-    else hipLaunchKernelGGL((attn_f16_v1<false, false>), grid, block, 0, s, qkv, out, L, Lq, H, nT, nWG, nBH, sl2e);
+    if (causal) hipLaunchKernelGGL(attn_f16_v1<true>, grid, block, 0, s, qkv, out, L, Lq, H, nT, nWG, nBH, sl2e);
+    else hipLaunchKernelGGL(attn_f16_v1<false>, grid, block, 0, s, qkv, out, L, Lq, H, nT, nWG, nBH, sl2e);
     return (int)hipGetLastError();
 }

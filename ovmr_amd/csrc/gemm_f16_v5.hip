@@ -577,7 +577,9 @@ __global__ __launch_bounds__(512) void gemm_f16_v5_kernel(GemmArgs a, int tiles_
                 if (LNF) {
 #pragma unroll
                     for (int r = 0; r < 4; r += 2) {
-                        const float2_t x2 = {fmaf(ln_r, v[r], fmaf(ln_t, c0[r], c1[r])), fmaf(ln_r, v[r + 1], fmaf(ln_t, c0[r + 1], c1[r + 1]))};
+                        // two columns per instruction (v_pk_fma_f32): same two fused multiply-adds per element as the scalar form
+                        const float2_t t2 = __builtin_elementwise_fma((float2_t){ln_t, ln_t}, (float2_t){c0[r], c0[r + 1]}, (float2_t){c1[r], c1[r + 1]});
+                        const float2_t x2 = __builtin_elementwise_fma((float2_t){ln_r, ln_r}, (float2_t){v[r], v[r + 1]}, t2);
                         half2_t u2 = __builtin_convertvector(x2, half2_t);
                         if (EPI == EPI_LN_BIAS_QGELU) u2 = quick_gelu_h2(u2);
                         o[r] = u2[0];

@@ -20,7 +20,7 @@ for name, B, L, H, causal in (("image", 512, 197, 12, 0), ("text", 1000, 10, 8, 
     out = torch.empty((B * L, H * 64), device="cuda", dtype=torch.float16)
     res = {}
     for r in range(3):
-        for v in (0, 1, 2, 3):
+        for v in (0, 1, 3):
             for _ in range(2):
                 assert lib.ovmr_debug_attention(0, v, p(qkv), p(out), B, L, H, causal, s()) == 0
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

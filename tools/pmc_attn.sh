@@ -17,9 +17,9 @@ for name in ("sq1", "sq2", "sq3", "mem"):
         agg = collections.defaultdict(lambda: collections.defaultdict(list))
         for r in csv.DictReader(open(f)):
             k = r["Kernel_Name"]
-            if "attn_f16_v1" not in k:
+            if "attn_f16" not in k:
                 continue
-            key = k.split("::")[-1].split("(")[0]                 # attn_f16_v1<causal, skip>: <false, true> = variant 1, <false, false> = variant 2
+            key = k.split("::")[-1].split("(")[0]                 # attn_f16_v3<13> = variant 3; attn_f16_v1<causal, skip>: <false, true> = variant 1, <false, false> = variant 2
             agg[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
             agg[key]["duration_us_under_pmc"].append((float(r["End_Timestamp"]) - float(r["Start_Timestamp"])) / 1e3)
         for key, c in agg.items():
