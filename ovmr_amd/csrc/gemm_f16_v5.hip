@@ -186,6 +186,8 @@ __global__ __launch_bounds__(512) void gemm_f16_v5_kernel(GemmArgs a, int tiles_
     // Slot reuse (WAR) follows the guide's rule: a half-tile is restaged >= 2 phases after its last fragment read (B0: one
     // phase after, its reads are retired by the lgkmcnt(8) in front of the reading phase's first barrier); a staged
     // half-tile is first read one phase after the counted wait + barrier that retires it (RAW).
+    // Measured and not kept (r02j): levelling the fragment reads to 8 / 4 / 8 / 4 per phase (next tile's B0 read in the fourth phase
+    // into the free B register set, wait moved to phases 3 / 7 with vmcnt(4)): bit-identical results, within +-1 % on every shape.
     // ------------------------------------------------------------------------------------------------------------------
     constexpr int SLOT = 16384, KBUF = 4 * SLOT;
     enum { hB0 = 0, hA0 = 1, hB1 = 2, hA1 = 3 };
@@ -283,79 +285,6 @@ __global__ __launch_bounds__(512) void gemm_f16_v5_kernel(GemmArgs a, int tiles_
     __builtin_amdgcn_sched_barrier(0);
     const char* const bufE = smem;
     const char* const bufO = smem + KBUF;
-    if constexpr ((OPT & 32) != 0) {
-    // ---- variant with LEVELLED fragment reads (OPT & 32): 8 / 4 / 8 / 4 per phase instead of 12 / 4 / 8 / 0.  The B0 fragments
-    // of the NEXT K-tile are read in the read-free fourth phase, into the B register set the current tile no longer needs (the two
-    // sets swap roles every K-tile: even tile B0 = fb0, B1 = fb1; odd tile B0 = fb1, B1 = fb0).  For that read to be legal the
-    // next tile must have landed one phase earlier, so the counted wait moves from phases 4 / 8 to phases 3 / 7 and leaves TWO
-    // half-tiles in flight (vmcnt(4)) instead of three.  Slot reuse: every half-tile is restaged two phases after its last read.
-    read_b(bufE, 0, fb0);                               // tile 0's B0 (landed: prologue wait + barrier)
-    __builtin_amdgcn_sched_barrier(0);
-    for (int kt = 0; kt < nk; kt += 2) {
-        const bool more = kt + 2 < nk;
-        // phase 1: (A0, B0 = fb0) of the even tile; stage A1 of the odd tile
-        read_a(bufE, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        stage_half(1, hA1, kt + 1);
-        OVMR_PH_MID((void)0)
-        quadrant(0, 0, fb0);
-        OVMR_PH_END()
-        // phase 2: (A0, B1 = fb1); stage B0 of tile kt+2 (last read: phase 8 of the previous iteration)
-        read_b(bufE, 1, fb1);
-        __builtin_amdgcn_sched_barrier(0);
-        if (more) stage_half(0, hB0, kt + 2);
-        OVMR_PH_MID((void)0)
-        quadrant(0, 1, fb1);
-        OVMR_PH_END()
-        // phase 3: (A1, B1 = fb1); stage A0 of tile kt+2; the odd tile must have landed: all but the two youngest half-tiles
-        read_a(bufE, 1);
-        __builtin_amdgcn_sched_barrier(0);
-        if (more) stage_half(0, hA0, kt + 2);
-        __builtin_amdgcn_sched_barrier(0);
-        if (more) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        OVMR_PH_MID((void)0)
-        quadrant(1, 1, fb1);
-        OVMR_PH_END()
-        // phase 4: (A1, B0 = fb0); read the ODD tile's B0 into fb1 (free since phase 3); stage B1 of tile kt+2
-        read_b(bufO, 0, fb1);
-        __builtin_amdgcn_sched_barrier(0);
-        if (more) stage_half(0, hB1, kt + 2);
-        OVMR_PH_MID(asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory"))
-        quadrant(1, 0, fb0);
-        OVMR_PH_END()
-        // phase 5: (A0, B0 = fb1) of the odd tile; stage A1 of tile kt+2
-        read_a(bufO, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        if (more) stage_half(0, hA1, kt + 2);
-        OVMR_PH_MID((void)0)
-        quadrant(0, 0, fb1);
-        OVMR_PH_END()
-        // phase 6: (A0, B1 = fb0); stage B0 of tile kt+3
-        read_b(bufO, 1, fb0);
-        __builtin_amdgcn_sched_barrier(0);
-        if (more) stage_half(1, hB0, kt + 3);
-        OVMR_PH_MID((void)0)
-        quadrant(0, 1, fb0);
-        OVMR_PH_END()
-        // phase 7: (A1, B1 = fb0); stage A0 of tile kt+3; tile kt+2 must have landed
-        read_a(bufO, 1);
-        __builtin_amdgcn_sched_barrier(0);
-        if (more) stage_half(1, hA0, kt + 3);
-        __builtin_amdgcn_sched_barrier(0);
-        if (more) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        OVMR_PH_MID((void)0)
-        quadrant(1, 1, fb0);
-        OVMR_PH_END()
-        // phase 8: (A1, B0 = fb1); read the next even tile's B0 into fb0; stage B1 of tile kt+3
-        if (more) read_b(bufE, 0, fb0);
-        __builtin_amdgcn_sched_barrier(0);
-        if (more) stage_half(1, hB1, kt + 3);
-        OVMR_PH_MID(asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory"))
-        quadrant(1, 0, fb1);
-        OVMR_PH_END()
-    }
-    } else
     for (int kt = 0; kt < nk; kt += 2) {
         const bool more = kt + 2 < nk;                  // tiles kt+2 / kt+3 exist (nk is even)
         // ---- phase 1: (A0, B0) of the even tile; stage A1 of the odd tile kt+1
@@ -793,8 +722,8 @@ int launch_v5(const GemmArgs& a, hipStream_t s) {
         static const int force = exp_env("OVMR_NT_STORE");
         b.nt_store = force ? force : (b.epi != EPI_BIAS_RES && (size_t)b.M * b.N * 2 >= ((size_t)48 << 20) ? 2 : 1);
     }
-    constexpr int P8 = OPT & (16 | 32);                 // 8-phase ping-pong K loop (256-row tiles; it replaces the OPT & 4 loop there); 32: levelled-read arm
-    constexpr bool PLAIN = (OPT & ~(16 | 32)) == 0;
+    constexpr int P8 = OPT & 16;                        // 8-phase ping-pong K loop (256-row tiles; it replaces the OPT & 4 loop there)
+    constexpr bool PLAIN = (OPT & ~16) == 0;
     constexpr bool OV_OK = !(P8 && MT == 8);
     if constexpr (PLAIN && OV_OK && (EPI == EPI_LN_BIAS || EPI == EPI_LN_BIAS_QGELU)) {
         // the LayerNorm-folding launches also run the K loop with the boundary inside the MFMA stream (qkv_ln 354 -> 343 us,
@@ -898,9 +827,6 @@ int launch_gemm_f16_v5(const GemmArgs& a, int variant, hipStream_t s) {
 #endif
         case 6: return dispatch_v5<0>(a, s);
         case 8: return (a.K % 128) == 0 ? dispatch_v5<16>(a, s) : dispatch_v5<0>(a, s);   // 8-phase K loop: two K-tiles per iteration
-#ifdef OVMR_EXPERIMENTS
-        case 9: return (a.K % 128) == 0 ? dispatch_v5<16 | 32>(a, s) : dispatch_v5<0>(a, s);   // A/B arm: levelled fragment reads, vmcnt(4)
-#endif
         default: return -5;                                                                // unknown variant
     }
 }
