@@ -235,3 +235,15 @@ def test_gemm_layernorm_fold(lib, variant, M, D, K1, N2, qgelu, produce):
     assert float((got - ref).abs().max()) <= tol, f"max err {(got - ref).abs().max()}"
     cos = torch.nn.functional.cosine_similarity(got, ref, dim=1)
     assert float((1 - cos).max()) < 1e-5
+
+
+def test_race_screen_of_hand_synchronised_kernels():
+    """GEMM variant 8 (counted vmcnt across barriers, wave rows one barrier apart) and attention variant 3 (LDS-DMA from inline
+    asm, hand-placed waits): repeated launches on fixed inputs, L2 / Infinity Cache thrashed in between, must reproduce the first
+    launch bit for bit (tools/race_screen.py; the per-shape comparisons against fp64 statements are the tests above)."""
+    import os
+    import subprocess
+    import sys
+    tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "race_screen.py")
+    r = subprocess.run([sys.executable, tool, "--reps", "60"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "RACE SCREEN CLEAN" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]

@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""Race screen for the hand-synchronised kernels (CDNA4 guide: "a sync-structure edit makes a NEW template: screen it for races
+over many runs at several sizes").  Every launch of a kernel on fixed inputs must reproduce the first launch bit for bit; the
+counted-vmcnt / staggered-barrier GEMM K loop (variant 8) and the persistent attention kernel with asm LDS-DMA (variant 3) are run
+--reps times per shape, interleaved with a cache-thrashing copy so that DMA arrival times vary.
+
+    python tools/race_screen.py [--reps 200]
+"""
+import argparse
+import ctypes
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from ovmr_amd import runtime
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--reps", type=int, default=200)
+a = ap.parse_args()
+lib = runtime.load_library()
+p = lambda t: ctypes.c_void_p(t.data_ptr())
+s = lambda: ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+junk = torch.empty(64 << 20, dtype=torch.float32, device="cuda")
+bad = 0
+for (M, N, K, epi) in ((4096, 1024, 768, 2), (5500, 768, 3072, 3), (2500, 2304, 768, 1), (100864, 3072, 768, 2), (100864, 768, 768, 3),
+                       (16400, 256, 128, 0), (50432, 768, 3072, 3), (8000, 1536, 512, 1)):
+    g = torch.Generator(device="cuda").manual_seed(M + N)
+    A = (torch.randn((M, K), generator=g, device="cuda") * 0.5).half()
+    W = (torch.randn((N, K), generator=g, device="cuda") * K ** -0.5).half()
+    b = (torch.randn((N,), generator=g, device="cuda") * 0.1).half()
+    res = torch.randn((M, N), generator=g, device="cuda").half()
+    ref, C = None, torch.empty_like(res)
+    reps = a.reps if M < 50000 else max(20, a.reps // 5)
+    mism = 0
+    for rep in range(reps):
+        C.copy_(res)
+        if rep % 3 == 0:
+            junk.add_(1.0)                                    # evict L2 / Infinity Cache contents between launches
+        assert lib.ovmr_debug_gemm(0, 8, p(A), p(W), p(b), p(C) if epi == 3 else None, None, p(C), M, N, K, N, epi, 1.0, 0, 0, s()) == 0
+        if ref is None:
+            ref = C.clone()
+        elif not torch.equal(C, ref):
+            mism += 1
+    bad += mism
+    print(f"gemm variant 8 {(M, N, K, epi)}: {reps} launches, {mism} differ from the first", flush=True)
+for (B, L, H) in ((512, 197, 12), (37, 197, 12), (3, 208, 4), (300, 193, 12)):
+    g = torch.Generator(device="cuda").manual_seed(B + L)
+    qkv = torch.randn((B * L, 3 * H * 64), generator=g, device="cuda").half()
+    out, ref, mism = torch.empty((B * L, H * 64), dtype=torch.float16, device="cuda"), None, 0
+    for rep in range(a.reps):
+        out.zero_()
+        if rep % 3 == 0:
+            junk.add_(1.0)
+        assert lib.ovmr_debug_attention(0, 3, p(qkv), p(out), B, L, H, 0, s()) == 0
+        if ref is None:
+            ref = out.clone()
+        elif not torch.equal(out, ref):
+            mism += 1
+    bad += mism
+    print(f"attention variant 3 {(B, L, H)}: {a.reps} launches, {mism} differ from the first", flush=True)
+torch.cuda.synchronize()
+print("RACE SCREEN", "CLEAN" if bad == 0 else f"FAILED ({bad} differing launches)")
+sys.exit(1 if bad else 0)
