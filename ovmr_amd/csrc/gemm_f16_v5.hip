@@ -172,22 +172,24 @@ __global__ __launch_bounds__(512) void gemm_f16_v5_kernel(GemmArgs a, int tiles_
 
     if constexpr ((OPT & 16) != 0 && MT == 8) {
     // ------------------------------------------------------------------------------------------------------------------
-    // 8-phase ping-pong K loop (OPT & 16; the 256x256 tile only).  Structure of the CDNA4 guide's "256^2 8-phase template":
+    // Ping-pong K loop (OPT & 16; the 256x256 tile only), after the CDNA4 guide's "256^2 8-phase template":
     //   * a K-tile is staged as FOUR 16 KiB half-tiles -- B0, A0, B1, A1 -- into 2 x 4 LDS slots (128 KiB as before);
     //     A half h holds the tile rows wm*128 + h*64 + [0,64) of BOTH wave rows, B half g the tile columns
-    //     wn*64 + g*32 + [0,32) of all four wave columns, so in phase (h, g) EVERY wave works on the same two half-tiles
+    //     wn*64 + g*32 + [0,32) of all four wave columns, so every wave works on the same half-tiles at the same time
     //     while its own 128 x 64 output block stays contiguous (the epilogue below is unchanged);
-    //   * four phases per K-tile, one 64 x 32 quadrant of the wave's block (16 MFMAs) each: (A0,B0) (A0,B1) (A1,B1) (A1,B0);
-    //     fragment reads: 12 / 4 / 8 / 0 per phase, every phase also issues ONE half-tile of LDS-DMA (2 instructions);
-    //   * the half-tiles of the next tiles are issued 3..4 phases ahead of their first read and the wait is COUNTED
-    //     (vmcnt(6) once per K-tile, never 0 inside the loop): three half-tiles stay in flight across the barriers;
+    //   * TWO phases per K-tile, two 64 x 32 quadrants of the wave's block (32 MFMAs) each: M1 reads B0, A0, B1 (16 fragment
+    //     reads) and runs (A0,B0) (A0,B1); M2 reads A1 (8) and runs (A1,B1) (A1,B0); every phase issues TWO half-tiles of
+    //     LDS-DMA (4 instructions per lane).  (r02: the template's FOUR 16-MFMA phases per K-tile ran first -- 12 / 4 / 8 / 0
+    //     reads, one half-tile per phase, vmcnt(6); same-process A/B of the two, bit-identical outputs: qkv 334 -> 313 us,
+    //     c_fc 478 -> 459, N = 768 shapes equal; end to end generation +1.4 %.  Half the barriers; levelling the four-phase
+    //     reads to 8 / 4 / 8 / 4 instead had changed nothing.)
+    //   * the half-tiles of the next tiles are issued two phases ahead of their first read and the wait is COUNTED (vmcnt(4)
+    //     once per K-tile, in M2, never 0 inside the loop): the two half-tiles just issued stay in flight across the barriers;
     //   * the two wave rows run ONE barrier apart: while wm = 0 issues its MFMAs, wm = 1 reads fragments and issues DMA,
     //     then they swap -- each SIMD holds one wave of either row, so its matrix pipe and its LDS / VMEM issue alternate.
-    // Slot reuse (WAR) follows the guide's rule: a half-tile is restaged >= 2 phases after its last fragment read (B0: one
-    // phase after, its reads are retired by the lgkmcnt(8) in front of the reading phase's first barrier); a staged
-    // half-tile is first read one phase after the counted wait + barrier that retires it (RAW).
-    // Measured and not kept (r02j): levelling the fragment reads to 8 / 4 / 8 / 4 per phase (next tile's B0 read in the fourth phase
-    // into the free B register set, wait moved to phases 3 / 7 with vmcnt(4)): bit-identical results, within +-1 % on every shape.
+    // Slot reuse (WAR): every phase retires its fragment reads (lgkmcnt(0)) BEFORE its first barrier, so a half-tile may be
+    // restaged one phase after its last read; a staged half-tile is first read one phase after the counted wait + barrier that
+    // retires it (RAW) -- the guide's rules for two wave groups staggered by a barrier.
     // ------------------------------------------------------------------------------------------------------------------
     constexpr int SLOT = 16384, KBUF = 4 * SLOT;
     enum { hB0 = 0, hA0 = 1, hB1 = 2, hA1 = 3 };
@@ -240,18 +242,12 @@ __global__ __launch_bounds__(512) void gemm_f16_v5_kernel(GemmArgs a, int tiles_
                     acc[hf * 4 + ii][g * 2 + jj] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[jj][st], fa[ii][st], acc[hf * 4 + ii][g * 2 + jj], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
     };
-#define OVMR_PH_MID(LGKM)                                                 \
-    __builtin_amdgcn_sched_barrier(0);                                    \
-    LGKM;                                                                 \
-    __builtin_amdgcn_s_barrier();                                         \
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                    \
-    __builtin_amdgcn_sched_barrier(0);
 #define OVMR_PH_END()                                                     \
     __builtin_amdgcn_sched_barrier(0);                                    \
     __builtin_amdgcn_s_barrier();                                         \
     __builtin_amdgcn_sched_barrier(0);
 
-    // prologue: tile 0 complete, three half-tiles of tile 1 in flight
+    // prologue: tile 0 complete, two half-tiles of tile 1 in flight
     stage_half(0, hB0, 0); stage_half(0, hA0, 0); stage_half(0, hB1, 0); stage_half(0, hA1, 0);
     // epilogue constants -> LDS (the compiler waits for their global loads with vmcnt(0), i.e. also for tile 0, which the first
     // phase needs anyway; first read after the K loop)
@@ -276,8 +272,8 @@ __global__ __launch_bounds__(512) void gemm_f16_v5_kernel(GemmArgs a, int tiles_
         row_c[BM + r] = -rstd * mean;
     }
     __builtin_amdgcn_sched_barrier(0);
-    stage_half(1, hB0, 1); stage_half(1, hA0, 1); stage_half(1, hB1, 1);
-    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    stage_half(1, hB0, 1); stage_half(1, hA0, 1);
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
@@ -285,74 +281,58 @@ __global__ __launch_bounds__(512) void gemm_f16_v5_kernel(GemmArgs a, int tiles_
     __builtin_amdgcn_sched_barrier(0);
     const char* const bufE = smem;
     const char* const bufO = smem + KBUF;
+#define OVMR_P4_MID()                                                     \
+    __builtin_amdgcn_sched_barrier(0);                                    \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                    \
+    __builtin_amdgcn_s_barrier();                                         \
+    __builtin_amdgcn_sched_barrier(0);
     for (int kt = 0; kt < nk; kt += 2) {
-        const bool more = kt + 2 < nk;                  // tiles kt+2 / kt+3 exist (nk is even)
-        // ---- phase 1: (A0, B0) of the even tile; stage A1 of the odd tile kt+1
+        const bool more = kt + 2 < nk;
+        // M1 even: stage B1, A1 of the odd tile
         read_b(bufE, 0, fb0);
-        __builtin_amdgcn_sched_barrier(0);
         read_a(bufE, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        stage_half(1, hA1, kt + 1);
-        OVMR_PH_MID(asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory"))
-        quadrant(0, 0, fb0);
-        OVMR_PH_END()
-        // ---- phase 2: (A0, B1); stage B0 of tile kt+2 (its slot was last read in phase 1)
         read_b(bufE, 1, fb1);
         __builtin_amdgcn_sched_barrier(0);
-        if (more) stage_half(0, hB0, kt + 2);
-        OVMR_PH_MID((void)0)
+        stage_half(1, hB1, kt + 1); stage_half(1, hA1, kt + 1);
+        OVMR_P4_MID()
+        quadrant(0, 0, fb0);
         quadrant(0, 1, fb1);
         OVMR_PH_END()
-        // ---- phase 3: (A1, B1); stage A0 of tile kt+2
+        // M2 even: stage B0, A0 of tile kt+2; the odd tile must have landed
         read_a(bufE, 1);
         __builtin_amdgcn_sched_barrier(0);
-        if (more) stage_half(0, hA0, kt + 2);
-        OVMR_PH_MID((void)0)
-        quadrant(1, 1, fb1);
-        OVMR_PH_END()
-        // ---- phase 4: (A1, B0), no fragment reads; stage B1 of tile kt+2; the odd tile must have landed: everything up to
-        //      phase 1's A1 -- three younger half-tiles (6 instructions) may stay in flight
-        if (more) stage_half(0, hB1, kt + 2);
+        if (more) { stage_half(0, hB0, kt + 2); stage_half(0, hA0, kt + 2); }
         __builtin_amdgcn_sched_barrier(0);
-        if (more) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        if (more) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        OVMR_PH_MID((void)0)
+        OVMR_P4_MID()
+        quadrant(1, 1, fb1);
         quadrant(1, 0, fb0);
         OVMR_PH_END()
-        // ---- phase 5: (A0, B0) of the odd tile; stage A1 of tile kt+2
+        // M1 odd: stage B1, A1 of tile kt+2
         read_b(bufO, 0, fb0);
-        __builtin_amdgcn_sched_barrier(0);
         read_a(bufO, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        if (more) stage_half(0, hA1, kt + 2);
-        OVMR_PH_MID(asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory"))
-        quadrant(0, 0, fb0);
-        OVMR_PH_END()
-        // ---- phase 6: (A0, B1); stage B0 of tile kt+3
         read_b(bufO, 1, fb1);
         __builtin_amdgcn_sched_barrier(0);
-        if (more) stage_half(1, hB0, kt + 3);
-        OVMR_PH_MID((void)0)
+        if (more) { stage_half(0, hB1, kt + 2); stage_half(0, hA1, kt + 2); }
+        OVMR_P4_MID()
+        quadrant(0, 0, fb0);
         quadrant(0, 1, fb1);
         OVMR_PH_END()
-        // ---- phase 7: (A1, B1); stage A0 of tile kt+3
+        // M2 odd: stage B0, A0 of tile kt+3; tile kt+2 must have landed
         read_a(bufO, 1);
         __builtin_amdgcn_sched_barrier(0);
-        if (more) stage_half(1, hA0, kt + 3);
-        OVMR_PH_MID((void)0)
-        quadrant(1, 1, fb1);
-        OVMR_PH_END()
-        // ---- phase 8: (A1, B0); stage B1 of tile kt+3; tile kt+2 must have landed (everything up to phase 5's A1)
-        if (more) stage_half(1, hB1, kt + 3);
+        if (more) { stage_half(1, hB0, kt + 3); stage_half(1, hA0, kt + 3); }
         __builtin_amdgcn_sched_barrier(0);
-        if (more) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        OVMR_PH_MID((void)0)
+        if (more) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        OVMR_P4_MID()
+        quadrant(1, 1, fb1);
         quadrant(1, 0, fb0);
         OVMR_PH_END()
     }
+#undef OVMR_P4_MID
     if (wm == 0) __builtin_amdgcn_s_barrier();          // balances the extra barrier of the second wave row
     __builtin_amdgcn_sched_barrier(0);
-#undef OVMR_PH_MID
 #undef OVMR_PH_END
     } else
     if (OPT & 4) {
@@ -722,7 +702,7 @@ int launch_v5(const GemmArgs& a, hipStream_t s) {
         static const int force = exp_env("OVMR_NT_STORE");
         b.nt_store = force ? force : (b.epi != EPI_BIAS_RES && (size_t)b.M * b.N * 2 >= ((size_t)48 << 20) ? 2 : 1);
     }
-    constexpr int P8 = OPT & 16;                        // 8-phase ping-pong K loop (256-row tiles; it replaces the OPT & 4 loop there)
+    constexpr int P8 = OPT & 16;                        // ping-pong K loop (256-row tiles; it replaces the OPT & 4 loop there)
     constexpr bool PLAIN = (OPT & ~16) == 0;
     constexpr bool OV_OK = !(P8 && MT == 8);
     if constexpr (PLAIN && OV_OK && (EPI == EPI_LN_BIAS || EPI == EPI_LN_BIAS_QGELU)) {
