@@ -508,6 +508,14 @@ __global__ __launch_bounds__(512) void gemm_f16_v5_kernel(GemmArgs a, int tiles_
         }
         return;
     }
+    auto gelu4 = [](half4_t v) -> half4_t {
+        if constexpr ((OPT & 32) != 0) {                // experiment builds: round 1's pairwise form, for the same-process A/B
+            const half2_t lo = quick_gelu_h2((half2_t){v[0], v[1]}), hi = quick_gelu_h2((half2_t){v[2], v[3]});
+            return (half4_t){lo[0], lo[1], hi[0], hi[1]};
+        } else {
+            return quick_gelu_h4(v);
+        }
+    };
     char* et = smem + wave * (64 * EP);                 // this wave's 64-row x 64-column staging tile
     const int er = lane >> 3, ec = (lane & 7) * 8;     // phase 2: row within an 8-row group, first column
     const bool emit_stats = EPI == EPI_BIAS_RES && a.stats_out != nullptr;
@@ -562,11 +570,11 @@ __global__ __launch_bounds__(512) void gemm_f16_v5_kernel(GemmArgs a, int tiles_
                         // two columns per instruction (v_pk_fma_f32): same two fused multiply-adds per element as the scalar form
                         const float2_t t2 = __builtin_elementwise_fma((float2_t){ln_t, ln_t}, (float2_t){c0[r], c0[r + 1]}, (float2_t){c1[r], c1[r + 1]});
                         const float2_t x2 = __builtin_elementwise_fma((float2_t){ln_r, ln_r}, (float2_t){v[r], v[r + 1]}, t2);
-                        half2_t u2 = __builtin_convertvector(x2, half2_t);
-                        if (EPI == EPI_LN_BIAS_QGELU) u2 = quick_gelu_h2(u2);
+                        const half2_t u2 = __builtin_convertvector(x2, half2_t);
                         o[r] = u2[0];
                         o[r + 1] = u2[1];
                     }
+                    if (EPI == EPI_LN_BIAS_QGELU) o = gelu4(o);
                 } else {
                     // float2 sums and __builtin_convertvector: v_pk_add_f32 + v_cvt_pk_f16_f32 (round to nearest even), two
                     // elements per instruction; element-wise casts made hipcc emit cvt + pack + alignbit chains (3.8 -> ~1.6
@@ -576,7 +584,6 @@ __global__ __launch_bounds__(512) void gemm_f16_v5_kernel(GemmArgs a, int tiles_
                         float2_t x2 = {v[r], v[r + 1]};
                         if (HAS_BIAS) x2 += (float2_t){c0[r], c0[r + 1]};
                         half2_t u2 = __builtin_convertvector(x2, half2_t);
-                        if (EPI == EPI_BIAS_QGELU) u2 = quick_gelu_h2(u2);
                         if (EPI == EPI_SCALE) {                                   // h(h(acc) * scale)
                             float2_t y2 = __builtin_convertvector(u2, float2_t);
                             y2 *= a.scale;
@@ -585,6 +592,7 @@ __global__ __launch_bounds__(512) void gemm_f16_v5_kernel(GemmArgs a, int tiles_
                         o[r] = u2[0];
                         o[r + 1] = u2[1];
                     }
+                    if (EPI == EPI_BIAS_QGELU) o = gelu4(o);
                 }
                 *(half4_t*)(et + (i * 16 + fr) * EP + (j * 16 + fg * 4) * 2) = o;
             }
@@ -702,9 +710,9 @@ int launch_v5(const GemmArgs& a, hipStream_t s) {
         static const int force = exp_env("OVMR_NT_STORE");
         b.nt_store = force ? force : (b.epi != EPI_BIAS_RES && (size_t)b.M * b.N * 2 >= ((size_t)48 << 20) ? 2 : 1);
     }
-    constexpr int P8 = OPT & 16;                        // ping-pong K loop (256-row tiles; it replaces the OPT & 4 loop there)
-    constexpr bool PLAIN = (OPT & ~16) == 0;
-    constexpr bool OV_OK = !(P8 && MT == 8);
+    constexpr int P8 = OPT & (16 | 32);                 // (32: experiment bit, rides along) ping-pong K loop (256-row tiles; it replaces the OPT & 4 loop there)
+    constexpr bool PLAIN = (OPT & ~(16 | 32)) == 0;
+    constexpr bool OV_OK = !((OPT & 16) && MT == 8);
     if constexpr (PLAIN && OV_OK && (EPI == EPI_LN_BIAS || EPI == EPI_LN_BIAS_QGELU)) {
         // the LayerNorm-folding launches also run the K loop with the boundary inside the MFMA stream (qkv_ln 354 -> 343 us,
         // c_fc_ln 525 -> 518 us; the plain bias / QuickGELU launches of the same shapes do not gain)
@@ -804,6 +812,7 @@ int launch_gemm_f16_v5(const GemmArgs& a, int variant, hipStream_t s) {
         case 19: return pick_v5<EPI_BIAS, 128>(a, s);
         case 28: return a.epi == EPI_BIAS_QGELU ? pick_v5<EPI_BIAS_QGELU, 16 | 64>(a, s) : pick_v5<EPI_BIAS, 16 | 64>(a, s);
         case 29: return pick_v5<EPI_BIAS, 16 | 128>(a, s);
+        case 38: return (a.K % 128) == 0 ? dispatch_v5<16 | 32>(a, s) : dispatch_v5<32>(a, s);   // variant 8 with the pairwise QuickGELU
 #endif
         case 6: return dispatch_v5<0>(a, s);
         case 8: return (a.K % 128) == 0 ? dispatch_v5<16>(a, s) : dispatch_v5<0>(a, s);   // 8-phase K loop: two K-tiles per iteration

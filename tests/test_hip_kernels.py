@@ -11,7 +11,7 @@ pytestmark = pytest.mark.gpu
 
 EPI_NONE, EPI_BIAS, EPI_BIAS_QGELU, EPI_BIAS_RES, EPI_PATCH, EPI_SCALE = range(6)
 GEMM_VARIANTS = [0, 6, 8]       # 0: 128x128 register-staged; 6 / 8: 256-row LDS-DMA tiles (double-buffered / 8-phase K loop)
-ATTN_VARIANTS = [0, 1, 3]
+ATTN_VARIANTS = [0, 1, 3, 4]
 
 
 @pytest.fixture(scope="module")

@@ -1,7 +1,12 @@
 #!/usr/bin/env python3
 """Times the fp16 attention kernel variants at the image-tower shape (B x 12 heads, L = 197) and the text shape."""
 import ctypes, json, os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+# variant 4's timing-only ablations (400 + mode, attention_v4.hip) live in the experiment build only
+_exp = os.path.join(ROOT, "ovmr_amd", "lib", "libovmr_hip_exp.so")
+if os.path.exists(_exp):
+    os.environ.setdefault("OVMR_HIP_LIB", _exp)
 import torch
 from ovmr_amd import runtime
 
@@ -9,6 +14,7 @@ import argparse
 ap = argparse.ArgumentParser()
 ap.add_argument("--only", default="")
 ap.add_argument("--reps", type=int, default=10)
+ap.add_argument("--variants", type=int, nargs="+", default=[0, 1, 3, 4])
 args = ap.parse_args()
 lib = runtime.load_library()
 p = lambda t: ctypes.c_void_p(t.data_ptr())
@@ -20,7 +26,7 @@ for name, B, L, H, causal in (("image", 512, 197, 12, 0), ("text", 1000, 10, 8, 
     out = torch.empty((B * L, H * 64), device="cuda", dtype=torch.float16)
     res = {}
     for r in range(3):
-        for v in (0, 1, 3):
+        for v in args.variants:
             for _ in range(2):
                 assert lib.ovmr_debug_attention(0, v, p(qkv), p(out), B, L, H, causal, s()) == 0
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -3,7 +3,7 @@
 # usage: tools/pmc_attn.sh <outdir>
 OUT=${1:-gpurun_out/pmc_attn}; R=${GRAFT_REPO_ROOT:-$(pwd)}
 mkdir -p $R/$OUT; cd /tmp; export TMPDIR=/tmp
-run() { name=$1; shift; timeout 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $R/$OUT/$name -- python3 $R/tools/attn_bench.py --only image --reps 2 > $R/$OUT/$name.log 2>&1; }
+run() { name=$1; shift; timeout 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $R/$OUT/$name -- python3 $R/tools/attn_bench.py --only image --reps 2 --variants ${VARIANTS:-0 1 3} > $R/$OUT/$name.log 2>&1; }
 run sq1 SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES GRBM_GUI_ACTIVE
 run sq2 SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_VALU SQ_ACTIVE_INST_VALU
 run sq3 SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_MISC SQ_ACTIVE_INST_SCA SQ_INSTS_LDS SQ_INSTS_SALU

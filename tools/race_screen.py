@@ -44,7 +44,8 @@ for (M, N, K, epi) in ((4096, 1024, 768, 2), (5500, 768, 3072, 3), (2500, 2304, 
             mism += 1
     bad += mism
     print(f"gemm variant 8 {(M, N, K, epi)}: {reps} launches, {mism} differ from the first", flush=True)
-for (B, L, H) in ((512, 197, 12), (37, 197, 12), (3, 208, 4), (300, 193, 12)):
+for variant in (3, 4):
+  for (B, L, H) in ((512, 197, 12), (37, 197, 12), (3, 208, 4), (300, 193, 12)):
     g = torch.Generator(device="cuda").manual_seed(B + L)
     qkv = torch.randn((B * L, 3 * H * 64), generator=g, device="cuda").half()
     out, ref, mism = torch.empty((B * L, H * 64), dtype=torch.float16, device="cuda"), None, 0
@@ -52,13 +53,13 @@ for (B, L, H) in ((512, 197, 12), (37, 197, 12), (3, 208, 4), (300, 193, 12)):
         out.zero_()
         if rep % 3 == 0:
             junk.add_(1.0)
-        assert lib.ovmr_debug_attention(0, 3, p(qkv), p(out), B, L, H, 0, s()) == 0
+        assert lib.ovmr_debug_attention(0, variant, p(qkv), p(out), B, L, H, 0, s()) == 0
         if ref is None:
             ref = out.clone()
         elif not torch.equal(out, ref):
             mism += 1
     bad += mism
-    print(f"attention variant 3 {(B, L, H)}: {a.reps} launches, {mism} differ from the first", flush=True)
+    print(f"attention variant {variant} {(B, L, H)}: {a.reps} launches, {mism} differ from the first", flush=True)
 torch.cuda.synchronize()
 print("RACE SCREEN", "CLEAN" if bad == 0 else f"FAILED ({bad} differing launches)")
 sys.exit(1 if bad else 0)
