@@ -14,8 +14,8 @@ and the queries are sharded over ranks (strong scaling of the named 1k-class job
 collectives are one all-gather of classifier rows and one all-reduce of the F1 counters.
 
 The JSON line also carries
-  roofline      the dominant kernel (fp16 MFMA GEMM at the c_fc launch shape of the job: M = batch x 197 = 100864 token
-                rows at batch 512, N = 3072, K = 768, ln_2 fold + bias + QuickGELU epilogue) timed live with HIP events
+  roofline      the dominant kernel (fp16 MFMA GEMM at the c_fc launch shape of the job: M = batch x 197 = 151296 token
+                rows at batch 768, N = 3072, K = 768, ln_2 fold + bias + QuickGELU epilogue) timed live with HIP events
                 on the stream it is launched on, against the 2.5 PFLOP/s dense fp16 MFMA peak;
   cpu_baseline  the CPU oracle (a torch-CPU port of the reference path, validated against golden vectors of
                 the real reference) timed on ALL of this host's cores (cores // 16 worker processes x 16 threads on disjoint
@@ -41,9 +41,11 @@ def parse():
     ap.add_argument("--classes", type=int, default=1000)
     ap.add_argument("--shots", type=int, default=16)
     ap.add_argument("--queries", type=int, default=4096)
-    ap.add_argument("--batch", type=int, default=512, help="exemplar images per encoder launch sequence")
+    ap.add_argument("--batch", type=int, default=768,
+                    help="exemplar images per encoder launch sequence (768 x 197 rows = 591 row tiles: 6.9 / 20.8 / 27.7 rounds of 256 CUs "
+                         "for the N = 768 / 2304 / 3072 GEMMs; 512 gives 4.6 rounds on N = 768, i.e. 8 % idle in the fifth)")
     ap.add_argument("--query-batch", type=int, default=256, help="query images per inference call (256 = BASELINE config 3)")
-    ap.add_argument("--classes-per-batch", type=int, default=256)
+    ap.add_argument("--classes-per-batch", type=int, default=240, help="classes per loader batch (x shots = a multiple of --batch)")
     ap.add_argument("--gemm", type=int, default=int(os.environ.get("OVMR_GEMM", "8")))
     ap.add_argument("--attn", type=int, default=int(os.environ.get("OVMR_ATTN", "3")))
     ap.add_argument("--ln-fold", type=int, default=int(os.environ.get("OVMR_LN_FOLD", "1")),
@@ -305,10 +307,12 @@ def measure_roofline(eng, spec, args, dev, n_exemplar_images, n_query_images):
             launch = lambda: lib.ovmr_debug_gemm(0, args.gemm, p(A), p(Wt), p(lb), p(st), p(lg), p(Cm), M, N, K, N, 7, 1.0, 0, 0, s())
         else:
             launch = lambda: lib.ovmr_debug_gemm(0, args.gemm, p(A), p(Wt), p(b), None, None, p(Cm), M, N, K, N, 2, 1.0, 0, 0, s())
-        for _ in range(5):
+        for _ in range(3):
             assert launch() == 0
         torch.cuda.synchronize()
-        reps = 30
+        # repetitions in proportion to the step's own mix, so that these extra launches do not shift the per-kernel average
+        # that `rocprofv3 --stats` reports for the same command
+        reps = max(3, round(30 * chunks[bsz] / max(chunks.values())))
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(reps):

@@ -7,12 +7,13 @@ run() { name=$1; shift; timeout 300 rocprofv3 --kernel-trace --pmc "$@" --output
 run sq1 SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES GRBM_GUI_ACTIVE
 run sq2 SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_VALU SQ_ACTIVE_INST_VALU
 run sq3 SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_MISC SQ_ACTIVE_INST_SCA SQ_INSTS_LDS SQ_INSTS_SALU
-run mem FETCH_SIZE WRITE_SIZE TCC_HIT_sum TCC_MISS_sum
+run fetch FETCH_SIZE
+run write WRITE_SIZE TCC_HIT_sum TCC_MISS_sum
 cd $R
 python3 - <<PY
 import csv, glob, collections, json
 out = collections.defaultdict(dict)
-for name in ("sq1", "sq2", "sq3", "mem"):
+for name in ("sq1", "sq2", "sq3", "fetch", "write"):
     for f in glob.glob("$OUT/%s/**/*counter_collection.csv" % name, recursive=True):
         agg = collections.defaultdict(lambda: collections.defaultdict(list))
         for r in csv.DictReader(open(f)):
@@ -25,6 +26,10 @@ for name in ("sq1", "sq2", "sq3", "mem"):
         for key, c in agg.items():
             for n, v in c.items():
                 out[key][n] = round(sum(v) / len(v), 2)
+for key, c in out.items():
+    if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+        # gfx950: FETCH_SIZE (KiB) reports half of the bytes of wide coalesced reads -> doubled (MI355X_MICROARCH.md, HBM)
+        c["hbm_bytes_per_launch"] = (2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024
 json.dump(out, open("$OUT/summary.json", "w"), indent=1)
 print(json.dumps(out, indent=1))
 PY
