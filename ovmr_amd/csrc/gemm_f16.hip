@@ -131,7 +131,7 @@ int launch_t128(const GemmArgs& a, hipStream_t s) {
 int launch_gemm_f16_v5(const GemmArgs& a, int variant, hipStream_t s);  // gemm_f16_v5.hip: 256(128)x256x64 LDS-DMA tiles, fused epilogues
 
 // variant 0: the 128x128 register-staged kernel above for every shape; 6: 256-row tiles with the double-buffered K loop;
-// 8 (default): 6 with the 8-phase ping-pong K loop.  6 / 8 fall back to the 128x128 kernel for shapes they do not take
+// 8 (default): 6 with the ping-pong K loop.  6 / 8 fall back to the 128x128 kernel for shapes they do not take
 // (M < 256, N < 128, ...).  Experiment builds (OVMR_EXPERIMENTS) add timing-only ablation variants (gemm_f16_v5.hip).
 int launch_gemm_f16(const GemmArgs& a, int variant, hipStream_t s) {
     if (a.M <= 0 || a.N <= 0) return 0;

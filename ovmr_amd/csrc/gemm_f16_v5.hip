@@ -1,7 +1,7 @@
 // fp16 MFMA GEMM, variants 6 and 8 (the default): 256(128)x256x64 tiles, both operands streamed into LDS by LDS-DMA
-// (global_load_lds, 16 B per lane, XOR-swizzled 128-byte rows), 8 waves as 2 x 4.  K loops: variant 8 = the 8-phase ping-pong
-// loop (four half-tiles per K-tile, counted vmcnt, the two wave rows one barrier apart: see OPT & 16 below; r02: qkv 369 -> 324,
-// c_fc 522 -> 479, c_proj 462 -> 390, out_proj 149 -> 133 us at batch 512); variant 6 = double buffer with a drain per K-tile
+// (global_load_lds, 16 B per lane, XOR-swizzled 128-byte rows), 8 waves as 2 x 4.  K loops: variant 8 = the ping-pong loop
+// (four half-tiles per K-tile, counted vmcnt, the two wave rows one barrier apart: see OPT & 16 below; r02: qkv 369 -> 312,
+// c_fc 522 -> 461, c_proj 462 -> 387, out_proj 149 -> 132 us at batch 512); variant 6 = double buffer with a drain per K-tile
 // and software-pipelined fragment reads (also the fallback of 8 for an odd number of K-tiles and for 128-row tiles).
 //
 // Epilogue (measured with tools/gemm_bench.py variants 6 / 18 / 19, profiles/r01g_gemm_epilogue.md: with K = 768 the
@@ -50,7 +50,7 @@ __device__ __forceinline__ float dpp_f32(float v) {
 }
 
 // OPT bits: 1 / 2 nontemporal LDS-DMA for the A / W operand, 4 K loop with the iteration boundary inside the MFMA stream,
-// 16 the 8-phase ping-pong K loop (256-row tiles), 64 NOSTORE / 128 NOEPI (timing-only ablations, experiment builds only),
+// 16 the ping-pong K loop (256-row tiles), 32 pairwise QuickGELU (experiment A/B), 64 NOSTORE / 128 NOEPI (timing-only ablations, experiment builds only),
 // 512 NT (nontemporal C stores)
 template <int EPI, int MT, int OPT>
 __global__ __launch_bounds__(512) void gemm_f16_v5_kernel(GemmArgs a, int tiles_m, int tiles_n) {
@@ -697,7 +697,7 @@ int launch_v5(const GemmArgs& a, hipStream_t s) {
         static const int force = exp_env("OVMR_N_GROUP");
         // measured (profiles/r01e_gemm_experiments.md): groups of 4-6 raise the L2 hit rate of qkv / c_fc from 65-68 %
         // to 72-73 % but move the run time by < 2 %, and hurt c_proj; the default therefore stays row-major (G = all)
-        // with the 8-phase K loop (r02c, same-process A/B at batch 512): groups of 4 N tiles take 1.5-2.5 % off qkv / c_fc
+        // with the ping-pong K loop (r02c, same-process A/B at batch 512): groups of 4 N tiles take 1.5-2.5 % off qkv / c_fc
         // (c_fc_ln 496 -> 484 us, qkv_ln 329 -> 325 us), nothing off the N = 768 shapes
         b.n_group = force > 0 ? std::min(force, tiles_n) : (((OPT & 16) && MT == 8 && tiles_n >= 8) ? 4 : tiles_n);
     }
@@ -760,7 +760,7 @@ int pick_v5(const GemmArgs& a, hipStream_t s) {
     bool big;
     if (g_force_mt) big = g_force_mt == 8;
     else if ((OPT & 16) && (a.K % 128) == 0) {
-        // 8-phase K loop on 256-row tiles against the double-buffered loop on 128-row tiles: a round of 128-row tiles takes
+        // ping-pong K loop on 256-row tiles against the double-buffered loop on 128-row tiles: a round of 128-row tiles takes
         // ~0.74 of a round of 256-row tiles (r02d, batch 256: out_proj 19.8 vs 26.6 us, c_proj 59 vs 78 us per round), so the
         // big tile wins unless the small one saves a whole round -- e.g. 591 tiles (batch 256, N = 768): 3 rounds against
         // 5 x 0.74; the CLS-only tail (6 tiles) stays on 128-row tiles.
@@ -771,6 +771,9 @@ int pick_v5(const GemmArgs& a, hipStream_t s) {
         // workgroups and shortens each K-tile (out_proj 22.5 -> 14.0 us, c_proj 67.7 -> 42.6 us at 512 rows)
         big = t256 >= 64 && eff(256) + 0.08 >= eff(128);
     }
+    // (r02q, measured and removed: running the rows beyond the last whole round of 256-row tiles as a second launch of 128-row
+    // tiles -- batch-256 inference, N = 768: 2.31 rounds -> 2 + 0.78 -- took 6 % off out_proj (81 -> 76 us) but added 2 % to
+    // c_proj (K = 3072: the small-tile round is no shorter there); 0.1 % of a step.)
     return big ? launch_v5<EPI, 8, OPT>(a, s) : launch_v5<EPI, 4, OPT>(a, s);
 }
 
@@ -792,7 +795,7 @@ int dispatch_v5(const GemmArgs& a, hipStream_t s) {
 
 }  // namespace
 
-// variant 8: the default (8-phase K loop); 6: the double-buffered K loop (also what 8 runs for an odd number of K-tiles and
+// variant 8: the default (ping-pong K loop); 6: the double-buffered K loop (also what 8 runs for an odd number of K-tiles and
 // for 128-row tiles)
 int launch_gemm_f16_v5(const GemmArgs& a, int variant, hipStream_t s) {
     if (a.epi == EPI_SCALE_ARGMAX) {
@@ -815,7 +818,7 @@ int launch_gemm_f16_v5(const GemmArgs& a, int variant, hipStream_t s) {
         case 38: return (a.K % 128) == 0 ? dispatch_v5<16 | 32>(a, s) : dispatch_v5<32>(a, s);   // variant 8 with the pairwise QuickGELU
 #endif
         case 6: return dispatch_v5<0>(a, s);
-        case 8: return (a.K % 128) == 0 ? dispatch_v5<16>(a, s) : dispatch_v5<0>(a, s);   // 8-phase K loop: two K-tiles per iteration
+        case 8: return (a.K % 128) == 0 ? dispatch_v5<16>(a, s) : dispatch_v5<0>(a, s);   // ping-pong K loop: two K-tiles per iteration
         default: return -5;                                                                // unknown variant
     }
 }

@@ -10,7 +10,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 EPI_NONE, EPI_BIAS, EPI_BIAS_QGELU, EPI_BIAS_RES, EPI_PATCH, EPI_SCALE = range(6)
-GEMM_VARIANTS = [0, 6, 8]       # 0: 128x128 register-staged; 6 / 8: 256-row LDS-DMA tiles (double-buffered / 8-phase K loop)
+GEMM_VARIANTS = [0, 6, 8]       # 0: 128x128 register-staged; 6 / 8: 256-row LDS-DMA tiles (double-buffered / ping-pong K loop)
 ATTN_VARIANTS = [0, 1, 3, 4]
 
 
@@ -97,11 +97,35 @@ def test_gemm_f16(lib, variant, M, N, K, epi):
 @pytest.mark.parametrize("M,N,K,epi", [
     (4096, 1024, 768, EPI_BIAS_QGELU), (2500, 2304, 768, EPI_BIAS), (5500, 768, 3072, EPI_BIAS_RES), (4096, 1000, 512, EPI_SCALE),
     (30 * 196, 768, 768, EPI_PATCH), (16400, 256, 128, EPI_NONE), (4097, 1280, 640, EPI_BIAS), (8200, 768, 256, EPI_BIAS_RES),
+    (50395, 768, 256, EPI_BIAS_RES), (66000, 1000, 128, EPI_SCALE),      # 2.31 / 4.03 rounds of 256 tiles
 ])
 def test_gemm_f16_large_tiles(lib, variant, M, N, K, epi):
     """Shapes with >= 64 tiles of 256 x 256, which take the 256-row tile kernels (variant 6: double-buffered K loop; variant 8:
-    8-phase ping-pong K loop; K = 640 has an odd number of K-tiles and must fall back), incl. ragged M / N edges."""
+    ping-pong K loop; K = 640 has an odd number of K-tiles and must fall back), incl. ragged M / N edges."""
     test_gemm_f16(lib, variant, M, N, K, epi)
+
+
+@pytest.mark.parametrize("M,N,K", [(66000, 1000, 128), (50395, 768, 256), (4100, 1003, 512)])
+def test_gemm_fused_row_argmax(lib, M, N, K):
+    """EPI_SCALE_ARGMAX (epi 8) against the argmax of the fp16 logits the EPI_SCALE epilogue of the same kernel writes: the
+    (maximum, lowest column) pair of every 256-column tile, bit for bit."""
+    g = torch.Generator().manual_seed(M + N)
+    A = torch.nn.functional.normalize(torch.randn(M, K, generator=g), dim=-1).half().cuda()
+    W = torch.nn.functional.normalize(torch.randn(N, K, generator=g), dim=-1).half()
+    W[N // 2] = W[3]                                        # an exact tie across tiles: the lower column must win
+    W = W.cuda()
+    tiles = (N + 255) // 256
+    logits = torch.empty((M, N), dtype=torch.float16, device="cuda")
+    pairs = torch.zeros((M, tiles, 2), dtype=torch.float32, device="cuda")
+    assert lib.ovmr_debug_gemm(0, 8, _p(A), _p(W), None, None, None, _p(logits), M, N, K, N, 5, 10.0, 0, 0, _s()) == 0
+    assert lib.ovmr_debug_gemm(0, 8, _p(A), _p(W), None, None, None, _p(pairs), M, N, K, tiles * 2, 8, 10.0, 0, 0, _s()) == 0
+    torch.cuda.synchronize()
+    lg = torch.nn.functional.pad(logits.float(), (0, tiles * 256 - N), value=float("-inf")).reshape(M, tiles, 256)
+    ref_v = lg.amax(dim=-1)
+    first = (lg == ref_v[..., None]).float().argmax(dim=-1)          # lowest column holding the maximum
+    cols = pairs[..., 1].contiguous().view(torch.int32)
+    assert torch.equal(pairs[..., 0], ref_v)
+    assert torch.equal(cols.long(), first + 256 * torch.arange(tiles, device="cuda")[None, :])
 
 
 @pytest.mark.parametrize("M,N,K,epi", [(36, 384, 128, EPI_BIAS), (288, 1536, 512, EPI_BIAS), (288, 512, 2048, EPI_BIAS_RES),
@@ -183,6 +207,7 @@ def test_attention_f32(lib, B, L, H):
     (197 * 3, 768, 768, 2304, 0, True), (1000, 768, 3072, 3072, 1, True), (256, 256, 64, 128, 0, True),
     (513, 512, 2048, 1536, 0, True), (300, 1024, 1024, 4096, 1, True), (462, 512, 0, 2048, 1, False),
     (197 * 28, 768, 768, 3072, 1, True), (5600, 768, 3072, 2304, 0, True),          # >= 64 tiles: the 256-row tile kernels
+    (197 * 256 - 19, 768, 256, 768, 1, True),     # the batch-256 launch shapes: 591 tiles = 2.31 rounds in both GEMMs
 ])
 def test_gemm_layernorm_fold(lib, variant, M, D, K1, N2, qgelu, produce):
     """EPI_BIAS_RES with the statistics epilogue, then LayerNorm folded into the next GEMM (common.h EPI_LN_BIAS):
@@ -238,7 +263,7 @@ def test_gemm_layernorm_fold(lib, variant, M, D, K1, N2, qgelu, produce):
 
 
 def test_race_screen_of_hand_synchronised_kernels():
-    """GEMM variant 8 (counted vmcnt across barriers, wave rows one barrier apart) and attention variant 3 (LDS-DMA from inline
+    """GEMM variant 8 (counted vmcnt across barriers, wave rows one barrier apart) and attention variants 3 / 4 (LDS-DMA from inline
     asm, hand-placed waits): repeated launches on fixed inputs, L2 / Infinity Cache thrashed in between, must reproduce the first
     launch bit for bit (tools/race_screen.py; the per-shape comparisons against fp64 statements are the tests above)."""
     import os

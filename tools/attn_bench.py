@@ -14,12 +14,13 @@ import argparse
 ap = argparse.ArgumentParser()
 ap.add_argument("--only", default="")
 ap.add_argument("--reps", type=int, default=10)
+ap.add_argument("--batch", type=int, default=512, help="images of the image-tower shape")
 ap.add_argument("--variants", type=int, nargs="+", default=[0, 1, 3, 4])
 args = ap.parse_args()
 lib = runtime.load_library()
 p = lambda t: ctypes.c_void_p(t.data_ptr())
 s = lambda: ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-for name, B, L, H, causal in (("image", 512, 197, 12, 0), ("text", 1000, 10, 8, 1), ("text77", 256, 77, 8, 1), ("vit-l336", 32, 577, 16, 0)):
+for name, B, L, H, causal in (("image", args.batch, 197, 12, 0), ("text", 1000, 10, 8, 1), ("text77", 256, 77, 8, 1), ("vit-l336", 32, 577, 16, 0)):
     if args.only and name != args.only:
         continue
     qkv = torch.randn((B * L, 3 * H * 64), device="cuda").half()
