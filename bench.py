@@ -300,26 +300,36 @@ def measure_roofline(eng, spec, args, dev, n_exemplar_images, n_query_images):
     lb, lg = torch.zeros(N, device=dev), torch.zeros(N, device=dev)
     st = torch.zeros((Mmax, K // 256, 2), device=dev)
     st[:, 0, 1] = float(K)                                            # mean 0, variance 1
+    # the launch in its context: the product path runs c_fc right behind out_proj, which has just written the residual
+    # stream and the row statistics c_fc reads -- so the probe launches that pair and times ONLY the c_fc launch (one
+    # event pair per launch).  Back-to-back repetitions of c_fc alone find their A operand warm in the Infinity Cache and
+    # read 3-4 % faster than the per-kernel average `rocprofv3 --kernel-trace --stats` reports for the real step.
+    A2 = (torch.randn((Mmax, K), generator=g, device=dev) * 0.01).half()
+    W2 = (torch.randn((K, K), generator=g, device=dev) * K ** -0.5).half()
+    b2 = torch.zeros(K, dtype=torch.float16, device=dev)
     shapes, tot_t, tot_f, tot_n = [], 0.0, 0.0, 0
     for bsz in sorted(chunks, reverse=True):
         M = bsz * L
         if args.ln_fold:   # the c_fc launch of the product path: ln_2 folded into the epilogue (csrc/common.h EPI_LN_BIAS_QGELU)
+            before = lambda: lib.ovmr_debug_gemm(0, args.gemm, p(A2), p(W2), p(b2), p(A), p(st), p(A), M, K, K, K, 3, 1.0, 0, 0, s())
             launch = lambda: lib.ovmr_debug_gemm(0, args.gemm, p(A), p(Wt), p(lb), p(st), p(lg), p(Cm), M, N, K, N, 7, 1.0, 0, 0, s())
         else:
+            before = lambda: 0
             launch = lambda: lib.ovmr_debug_gemm(0, args.gemm, p(A), p(Wt), p(b), None, None, p(Cm), M, N, K, N, 2, 1.0, 0, 0, s())
         for _ in range(3):
-            assert launch() == 0
+            assert before() == 0 and launch() == 0
         torch.cuda.synchronize()
         # repetitions in proportion to the step's own mix, so that these extra launches do not shift the per-kernel average
         # that `rocprofv3 --stats` reports for the same command
         reps = max(3, round(30 * chunks[bsz] / max(chunks.values())))
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(reps):
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+        for e0, e1 in ev:
+            before()
+            e0.record()
             launch()
-        e1.record()
+            e1.record()
         torch.cuda.synchronize()
-        us = e0.elapsed_time(e1) * 1000.0 / reps
+        us = sum(e0.elapsed_time(e1) for e0, e1 in ev) * 1000.0 / reps
         n = chunks[bsz] * layers
         shapes.append({"M": M, "launches_per_step": n, "avg_launch_us": round(us, 2), "tflops": round(2.0 * M * N * K / us / 1e6, 1)})
         tot_t += n * us

@@ -1,8 +1,17 @@
 #!/bin/bash
-python -m pytest tests -m gpu -x -q 2>&1 | tail -4 > gpurun_out/r02j_pytest.log
-python tools/xval_bench.py --classes 10000 --shots 8 > gpurun_out/r02j_xval_c10000_s8.log 2>&1
-python tools/xval_bench.py --classes 1000 --shots 16 > gpurun_out/r02j_xval_c1000_s16.log 2>&1
-OVMR_DIST_BACKEND=gloo HSA_ENABLE_IPC_MODE_LEGACY=0 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 2 --warmup 1 --classes 200 --queries 1024 --no-cpu-baseline > gpurun_out/r02j_bench_gloo2.log 2>&1
-python bench.py --steps 2 --warmup 1 --classes 200 --queries 1024 --no-cpu-baseline > gpurun_out/r02j_bench_n1_small.log 2>&1
-tail -3 gpurun_out/r02j_pytest.log; tail -1 gpurun_out/r02j_xval_c10000_s8.log; tail -1 gpurun_out/r02j_xval_c1000_s16.log
-for f in gpurun_out/r02j_bench_gloo2.log gpurun_out/r02j_bench_n1_small.log; do echo == $f; grep "^{\"metric" $f | cut -c1-330 || tail -5 $f; done; tail -5 gpurun_out/r02j_bench_gloo2.log | cut -c1-300
+# final GPU pass of the round (tag $1): whole -m gpu suite, smoke, default bench, the same bench under rocprofv3 --stats
+T=${1:-r02t}
+mkdir -p gpurun_out
+timeout 1800 python -m pytest tests -m gpu -x -q > gpurun_out/${T}_pytest.log 2>&1; tail -2 gpurun_out/${T}_pytest.log
+timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/${T}_smoke.log 2>&1; tail -2 gpurun_out/${T}_smoke.log
+timeout 900 python bench.py > gpurun_out/${T}_bench.log 2>&1; grep '^{"metric' gpurun_out/${T}_bench.log > gpurun_out/${T}_bench_n1.json; cut -c1-260 gpurun_out/${T}_bench_n1.json
+R=$(pwd); cd /tmp; export TMPDIR=/tmp
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${T}_stats -- python3 $R/bench.py --steps 3 --warmup 1 --cpu-sample-classes 0 > $R/gpurun_out/${T}_stats_bench.log 2>&1
+cd $R
+f=$(find gpurun_out/${T}_stats -name "*kernel_stats.csv" | head -1); cp $f gpurun_out/${T}_kernel_stats.csv; head -5 $f | cut -c1-200
+grep '^{"metric' gpurun_out/${T}_stats_bench.log > gpurun_out/${T}_bench_under_rocprof.json
+python3 - <<PY
+import json
+d = json.load(open("gpurun_out/${T}_bench_under_rocprof.json"))
+print("under rocprof:", d["value"], d["roofline"]["avg_launch_us"], d["roofline"]["launches_per_step"], d["roofline"]["frac"])
+PY
