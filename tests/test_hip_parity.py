@@ -418,6 +418,25 @@ def test_full_size_properties():
     e.finalize(64, 64, 256)
 
 
+def test_attention_variants_agree_inside_the_encoder():
+    """ViT-B/16 image features with every attention kernel that takes L = 197 (variants 1, 3, 4) through the whole encoder:
+    variants 3 and 4 share their tile arithmetic and must agree bit for bit; the flash-style variant 1 within fp16 rounding."""
+    cm = _clip("ViT-B/16")
+    e = cm.engine(2)
+    e.finalize(64, 64, 256)
+    g = torch.Generator(device="cuda").manual_seed(11)
+    img = torch.randn(37, 3, 224, 224, generator=g, device="cuda", dtype=torch.float16)
+    f = {}
+    try:
+        for v in (3, 4, 1):
+            e.set_option("attn", v)
+            f[v] = e.encode_image(img, normalize=True).clone()
+    finally:
+        e.set_option("attn", 3)
+    assert torch.equal(f[3], f[4])
+    assert_cosine(f[1].float().cpu().numpy(), f[3].float().cpu().numpy(), 1e-5, "attention variant 1 vs 3")
+
+
 def test_cli_generate_and_evaluate_end_to_end(tmp_path, O):
     """SURVEY 8f-1/2/3/4 together: folder dataset -> PIL test transform -> BPE tokenizer -> checkpoint files ->
     CustomCLIP on the HIP path -> mm_classifiers.pt + per-class CSVs; classifier rows checked against the oracle."""
