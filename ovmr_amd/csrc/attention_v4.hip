@@ -1,9 +1,12 @@
 // Attention variant 4 (fp16, hd = 64, non-causal, 192 < L <= 208): variant 3's single pass over the keys with the workgroup
 // barrier taken out.
 //
-// Variant 3 gives wave w query tile w of the head and meets at ONE barrier per head.  13 tiles over 4 SIMDs is 4 + 3 + 3 + 3:
-// the SIMD holding four tile waves sets the pace of every head (4 tile times against an average of 3.25) and the other three
-// idle at the barrier; that, not the memory system, is why a third K / V buffer and head-major strides changed nothing.
+// Variant 3 gives wave w query tile w of the head and meets at ONE barrier per head.  13 tiles over 4 SIMDs is 4 + 3 + 3 + 3, so
+// the SIMD holding four tile waves sets the pace of every head while the other three idle at the barrier.  This variant was
+// written to remove that -- and to find out what bounds the kernel once it is gone.  Answer (r02m / r02n, the timing-only modes
+// at the bottom of this file): the memory system.  Balanced, barrier-free waves run at the same 135-140 us as
+// variant 3; with the output stores removed 108-115 us; with the tile arithmetic removed as well 82 us.  It is kept as an
+// alternative ("attn" = 4) with identical results, and as the harness of those ablations.
 // Here the waves of the persistent workgroup never meet:
 //   * 12 CONSUMER waves, three per SIMD, take the CU's (head, query tile) list round-robin -- tile t = c, c + 12, c + 24, ... of
 //     13 x heads-per-CU tiles -- so every SIMD carries the same load whatever 13 mod 4 is, and the waves drift apart in phase,
@@ -109,8 +112,8 @@ __global__ __launch_bounds__(NW4 * 64) void attn_f16_v4(const half_t* __restrict
     };
     int t = wave;
     if (t >= ntiles) return;
-    // VMEM traffic of a consumer is the same straight line every tile -- two query loads for the NEXT tile at the top, four
-    // stores at the end -- so the wait in front of a tile's first MFMA is a counted vmcnt(6): stores and the next rows stay in
+    // VMEM traffic of a consumer is the same straight line every tile -- two query loads for the NEXT tile at the top, two
+    // stores at the end -- so the wait hipcc inserts in front of `qf = qn` is a counted vmcnt(2): the stores stay in
     // flight.  (Conditional loads / stores made hipcc wait vmcnt(0) there: query latency exposed on every tile.)
     half8_t qf[2], qn[2];
     load_q(t, qf);
