@@ -18,7 +18,7 @@ The JSON line also carries
                 rows at batch 768, N = 3072, K = 768, ln_2 fold + bias + QuickGELU epilogue) timed live with HIP events
                 on the stream it is launched on, against the 2.5 PFLOP/s dense fp16 MFMA peak;
   cpu_baseline  the CPU oracle (a torch-CPU port of the reference path, validated against golden vectors of
-                the real reference) timed on ALL of this host's cores (cores // 16 worker processes x 16 threads on disjoint
+                the real reference) timed on the CPUs this process may use (the cgroup quota, not the whole host: usable // 16 worker processes x 16 threads on disjoint
                 class slices, 1 warm-up + 3 timed repetitions, median) on a bounded sample (rank 0, N = 1 only).
 """
 import argparse
@@ -51,6 +51,11 @@ def parse():
     ap.add_argument("--ln-fold", type=int, default=int(os.environ.get("OVMR_LN_FOLD", "1")),
                     help="1: ln_1/ln_2 folded into the consuming GEMM epilogue; 0: separate LayerNorm kernels")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="N = 1 only: initialise a one-rank nccl (= RCCL) process group and take the sharded path, so that the packed "
+                         "all-gather and the counter all-reduce run through librccl on this GPU")
+    ap.add_argument("--gelu-exact", type=int, default=int(os.environ.get("OVMR_GELU_EXACT", "0")),
+                    help="1: QuickGELU with the reference's three fp16 rounding points; 0 (engine default): one rounding, fp32")
     ap.add_argument("--cpu-sample-classes", type=int, default=2, help="classes per CPU worker process and repetition (0: skip)")
     ap.add_argument("--cpu-threads", type=int, default=16, help="threads per CPU worker process")
     ap.add_argument("--cpu-reps", type=int, default=3)
@@ -81,12 +86,14 @@ def main():
     backend = os.environ.get("OVMR_DIST_BACKEND", "nccl")
     dev = torch.device(f"cuda:{local if backend == 'nccl' else local % max(1, torch.cuda.device_count())}")
     torch.cuda.set_device(dev)
-    if world > 1:
+    sharded = world > 1 or args.force_dist          # the class-sharded path with its two collectives
+    if sharded:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29512")
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     spec = synth.SPECS[args.model]
     C, S, Q, n_ctx = args.classes, args.shots, args.queries, 2
@@ -102,8 +109,9 @@ def main():
                            test_batch_size=args.batch)
     tok = torch.from_numpy(synth.class_token_ids(C, seed=4321))
     model = modules.CustomCLIP(cfg, tok, cm, prompt_learner_state=pl,
-                               reserve=(args.batch, max(256, min(C, 2048)), max(C, 1024)))
+                               reserve=(args.batch, max(256, min(C, 2048)), max(C, 1024)), distributed=sharded)
     eng = model.engine
+    eng.set_option("gelu_exact", args.gelu_exact)
     eng.set_option("gemm", args.gemm)
     eng.set_option("attn", args.attn)
     eng.set_option("ln_fold", args.ln_fold)
@@ -119,7 +127,7 @@ def main():
     loader = ResidentEvalSet(ex_img, torch.arange(c0, c1, device=dev), S, args.classes_per_batch, presharded=True)
 
     def step():
-        if world == 1:
+        if not sharded:
             model.zero_shot_classifier = model.prompt_learner.zero_shot_classifier = \
                 model.prompt_learner.encode_zero_shot(model.tokenized_prompts)     # part of the job (:118-126)
         model.forward_prompt(loader)
@@ -129,7 +137,7 @@ def main():
         return outs
 
     def barrier():
-        if world > 1:
+        if sharded:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -140,12 +148,12 @@ def main():
     for _ in range(args.steps):
         out = step()
     torch.cuda.synchronize()
-    if world > 1:
+    if sharded:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if world > 1:
+    if sharded:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
     assert out is None or bool(torch.isfinite(out).all())
@@ -174,8 +182,9 @@ def main():
             "vs_baseline": None, "dtype": "f16", "data": "synthetic",
             "config": {"workload": f"OVMR classifier generation + fusion inference, {args.model}, {C} classes x {S} shots "
                                    f"({C * S} exemplar images, batch {args.batch}) + {Q} query images (batch {args.query_batch}), n_ctx 2, tau 10",
-                       "parallelism": f"class/query sharding over {world} rank(s); all-gather rows + all-reduce counters",
-                       "gemm_variant": args.gemm, "attn_variant": args.attn, "ln_fold": args.ln_fold,
+                       "parallelism": f"class/query sharding over {world} rank(s); all-gather rows + all-reduce counters"
+                                      + (f" (process group {dist.get_backend()}, sharded path forced)" if args.force_dist and world == 1 else ""),
+                       "gemm_variant": args.gemm, "attn_variant": args.attn, "ln_fold": args.ln_fold, "gelu_exact": args.gelu_exact,
                        "images_per_step": images_per_step},
             "roofline": roof,
             "cpu_baseline": cpu,
@@ -187,9 +196,11 @@ def main():
                        "e2e_frac_of_fp16_mfma_peak": round(value * flops_run / 1e12 / (2500.0 * world), 4)},
         }
         if cpu and cpu.get("value"):
+            # one GPU against the CPUs the cgroup grants this job (cpu["cores"] threads), NOT against the whole host
             line["gpu_over_cpu"] = round(value / cpu["value"], 1)
+            line["gpu_over_cpu_note"] = f"1 GPU vs {cpu['cores']} CPU threads (of {cpu.get('host_cores')} on the host)"
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if sharded:
         dist.barrier()
         dist.destroy_process_group()
 
@@ -308,14 +319,15 @@ def measure_roofline(eng, spec, args, dev, n_exemplar_images, n_query_images):
     W2 = (torch.randn((K, K), generator=g, device=dev) * K ** -0.5).half()
     b2 = torch.zeros(K, dtype=torch.float16, device=dev)
     shapes, tot_t, tot_f, tot_n = [], 0.0, 0.0, 0
+    gv = args.gemm + (0 if args.gelu_exact else 100)                 # kernel + QuickGELU form, as the engine launches c_fc
     for bsz in sorted(chunks, reverse=True):
         M = bsz * L
         if args.ln_fold:   # the c_fc launch of the product path: ln_2 folded into the epilogue (csrc/common.h EPI_LN_BIAS_QGELU)
             before = lambda: lib.ovmr_debug_gemm(0, args.gemm, p(A2), p(W2), p(b2), p(A), p(st), p(A), M, K, K, K, 3, 1.0, 0, 0, s())
-            launch = lambda: lib.ovmr_debug_gemm(0, args.gemm, p(A), p(Wt), p(lb), p(st), p(lg), p(Cm), M, N, K, N, 7, 1.0, 0, 0, s())
+            launch = lambda: lib.ovmr_debug_gemm(0, gv, p(A), p(Wt), p(lb), p(st), p(lg), p(Cm), M, N, K, N, 7, 1.0, 0, 0, s())
         else:
             before = lambda: 0
-            launch = lambda: lib.ovmr_debug_gemm(0, args.gemm, p(A), p(Wt), p(b), None, None, p(Cm), M, N, K, N, 2, 1.0, 0, 0, s())
+            launch = lambda: lib.ovmr_debug_gemm(0, gv, p(A), p(Wt), p(b), None, None, p(Cm), M, N, K, N, 2, 1.0, 0, 0, s())
         for _ in range(3):
             assert before() == 0 and launch() == 0
         torch.cuda.synchronize()
@@ -338,31 +350,38 @@ def measure_roofline(eng, spec, args, dev, n_exemplar_images, n_query_images):
     achieved = tot_f / (tot_t * 1e-6) / 1e12
     Mfull = max(chunks) * L
     return {"bound": "mfma",
-            "kernel": f"gemm_f16 variant {args.gemm}, c_fc launches N={N} K={K} ({'ln_2 fold + ' if args.ln_fold else ''}bias + QuickGELU), "
+            "kernel": f"gemm_f16 variant {args.gemm}, c_fc launches N={N} K={K} ({'ln_2 fold + ' if args.ln_fold else ''}bias + QuickGELU{'' if args.gelu_exact else ', one rounding'}), "
                       f"launch-weighted over the M of one step",
             "achieved": round(achieved, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(achieved / 2500.0, 4),
             "avg_launch_us": round(tot_t / tot_n, 2), "flops_per_launch": tot_f / tot_n, "launches_per_step": tot_n, "shapes": shapes,
-            **pmc_traffic(args.gemm, Mfull, N, args.batch, 7 if args.ln_fold else 2)}
+            **pmc_traffic(gv, Mfull, N, args.batch, 7 if args.ln_fold else 2)}
 
 
 def pmc_traffic(variant, M, N, batch, epi=2):
-    """HBM bytes per launch of that kernel from the committed PMC summary (tools/pmc_gemm.sh: separate rocprofv3 --pmc
-    passes, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950) -- null when no summary matches."""
+    """Counters of that kernel from the committed PMC summary (tools/pmc_gemm.sh: separate rocprofv3 --pmc passes over the
+    product library, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950): HBM-side bytes per launch and rate,
+    matrix-pipe busy fraction (SQ_VALU_MFMA_BUSY_CYCLES / (cycles x 1024 pipes)), LDS bank-conflict fraction, held clock.
+    A summary is used only if it was taken on the SAME kernel sources (ovmr_amd.build.source_sha16) -- otherwise null."""
     import glob
+    from ovmr_amd.build import source_sha16
+    sha = source_sha16()
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", f"*pmc_gemm_v{variant}.json")), reverse=True):
         try:
             d = json.load(open(f))
-            if d.get("batch") != batch:
+            if d.get("batch") != batch or d.get("kernel_source_sha16") != sha:
                 continue
             for key, c in d["kernels"].items():
                 for bm in (256, 128):
                     grid = ((M + bm - 1) // bm) * ((N + 255) // 256) * 512
                     if key.endswith(f"grid={grid}") and f"<{epi}," in key and "hbm_bytes_per_launch" in c:
                         return {"traffic": c["hbm_bytes_per_launch"], "traffic_unit": f"bytes/launch at M={M}",
-                                "traffic_source": os.path.relpath(f, ROOT), "algorithmic_bytes": 2.0 * (M * (N // 4) + N * (N // 4) + M * N)}
+                                "traffic_source": os.path.relpath(f, ROOT), "algorithmic_bytes": 2.0 * (M * (N // 4) + N * (N // 4) + M * N),
+                                "hbm_gbps": c.get("hbm_gbps"), "hbm_frac_of_8tbps": round(c["hbm_gbps"] / 8000.0, 4) if c.get("hbm_gbps") else None,
+                                "mfma_busy_frac": c.get("mfma_busy_frac"), "lds_conflict_frac": c.get("lds_conflict_frac"),
+                                "clock_ghz_under_pmc": c.get("clock_ghz"), "kernel_source_sha16": sha}
         except Exception:
             pass
-    return {"traffic": None}
+    return {"traffic": None, "kernel_source_sha16": sha}
 
 
 def _cpu_worker(widx, nproc, threads, spec_name, sd16, pl, tok, shots, classes, reps, n_ctx, barrier, queue):
@@ -488,7 +507,8 @@ def cpu_baseline(spec, sd, pl, tok, args, n_ctx):
         pass
     return {"value": round(max(v16, v32), 2), "unit": "images/s", "cores": nproc * threads, "kind": "port",
             "sample": f"{nproc} worker processes x {threads} threads, each {Cs} class(es) x {S} shots generation + 4 fusion queries "
-                      f"(batch {Cs * S}) on its own class slice, 1 warm-up + {args.cpu_reps} timed repetitions, median; whole host "
+                      f"(batch {Cs * S}) on its own class slice, 1 warm-up + {args.cpu_reps} timed repetitions, median; "
+                      f"{nproc * threads} threads = the {cores} CPUs this process may use (cgroup quota) of {os.cpu_count()} host threads: "
                       f"fp32 math on fp16-rounded weights {v32:.1f} img/s, fp16 {v16:.1f} img/s, faster reported; "
                       f"{t_all:.0f} s wall incl. process start",
             "host_cores": os.cpu_count(), "usable_cpus": cores, "cgroup_cpu_quota": quota, "cpu_model": model, "processes": nproc, "threads_per_process": threads,

@@ -10,7 +10,7 @@
  *     allocates, passes tensor.data_ptr()); the library owns only its weight arena and workspace;
  *   - every compute call is asynchronous on the caller's hipStream_t, performs no allocation and
  *     no host synchronisation (graph-capturable), and may be called with any batch size up to
- *     what ovmr_reserve() sized (larger batches are processed in chunks);
+ *     what ovmr_finalize() sized the workspace for (larger batches are processed in chunks);
  *   - return value: 0 = ok, otherwise an OVMR_E_* code or a positive hipError_t;
  *     ovmr_last_error(h) returns a message for the last failure on that handle;
  *   - one handle per (device, model, stream user): thread-compatible, not thread-safe;
@@ -62,7 +62,7 @@ void ovmr_destroy(ovmr_handle* h);
 const char* ovmr_last_error(const ovmr_handle* h);
 const char* ovmr_version(void);
 
-/* Kernel-variant switch used by tests/bench to A/B implementations: key in {"gemm","attn","ln_fold","xval_fused"}.
+/* Kernel-variant switch used by tests/bench to A/B implementations: key in {"gemm","attn","ln_fold","xval_fused","gelu_exact"}.
  * "gemm" (default 8): 8 = 256-row LDS-DMA tiles with the ping-pong K loop (half-tile staging, counted waits), 6 = the same tiles with the double-buffered
  *   K loop, 0 = the 128x128 register-staged kernel everywhere (LayerNorm-folding and fused-argmax launches still take the tile kernel).
  * "attn" (default 3): 3 = single-pass persistent kernel where the shape is its own (non-causal, 192 < L <= 208), else as 1;
@@ -71,7 +71,11 @@ const char* ovmr_version(void);
  * "ln_fold" (default 1): ln_1 / ln_2 of the fp16 towers are folded into the consuming GEMM where the shape allows
  *   (width % 256 == 0 and >= 256 token rows); 0 runs the separate LayerNorm kernel everywhere.
  * "xval_fused" (default 1): ovmr_xval_counts takes the row argmax inside the logits GEMM's epilogue (the [R, C] logits are never
- *   written); 0 materialises fp16 logits in workspace chunks and runs a row-argmax kernel on them.  Identical counters. */
+ *   written); 0 materialises fp16 logits in workspace chunks and runs a row-argmax kernel on them.  Identical counters.
+ * "gelu_exact" (default 0): QuickGELU of the c_fc epilogue (clip/model.py:162-164).  1 keeps the three fp16 rounding points of the
+ *   reference's fp16 tensors (h(1.702 u), h(sigmoid), h(u s)); 0 evaluates x / (1 + exp(-1.702 x)) in fp32 on the unrounded
+ *   linear output and rounds once -- closer to the real function, within a few fp16 steps of the reference's value, and 5 % off
+ *   the c_fc launch. */
 int ovmr_set_option(ovmr_handle* h, const char* key, int value);
 
 /* Weight ingestion -- replaces build_model()/convert_weights()/load_state_dict

@@ -20,6 +20,17 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-mcode-object-v
          "-Wno-unused-result", "-ffp-contract=off"]
 
 
+def source_sha16(names=("gemm_f16_v5.hip", "common.h")) -> str:
+    """sha256[:16] of kernel sources: profiles/*pmc*.json carry it so that bench.py refuses a counter summary taken on
+    other code than the one it is timing."""
+    import hashlib
+    h = hashlib.sha256()
+    for n in names:
+        with open(os.path.join(CSRC, n), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
 def _stale(out, deps):
     if not os.path.exists(out):
         return True

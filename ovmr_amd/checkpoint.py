@@ -46,11 +46,24 @@ def prompt_learner_checkpoint_path(directory: str, epoch: Optional[int] = None, 
     return best
 
 
-def load_prompt_learner_state(directory: str, epoch: Optional[int] = None) -> Dict[str, torch.Tensor]:
-    path = prompt_learner_checkpoint_path(directory, epoch)
+def _torch_load(path: str):
+    """Tensors, ints and dicts are all these files need: unpickle with weights_only=True, and fall back to full unpickling (which
+    can execute code from the file -- what the reference's load_checkpoint always does) only when that fails, with a warning."""
+    import pickle
+    import warnings
+    try:
+        return torch.load(path, map_location="cpu", weights_only=True)
+    except (pickle.UnpicklingError, RuntimeError) as e:
+        warnings.warn(f'"{path}" needs full unpickling ({str(e).splitlines()[0][:120]}); loading it with weights_only=False')
+        return torch.load(path, map_location="cpu", weights_only=False)
+
+
+def load_prompt_learner_checkpoint(directory: str, epoch: Optional[int] = None, name: str = "prompt_learner"):
+    """(state dict without token_prefix / token_suffix, epoch recorded in the file, path) of a Dassl checkpoint."""
+    path = prompt_learner_checkpoint_path(directory, epoch, name)
     if not osp.exists(path):
         raise FileNotFoundError('Model not found at "{}"'.format(path))          # same message as :477-478
-    ckpt = torch.load(path, map_location="cpu", weights_only=False)
+    ckpt = _torch_load(path)
     sd = ckpt["state_dict"] if "state_dict" in ckpt else ckpt
     out = OrderedDict()
     for k, v in sd.items():
@@ -59,7 +72,11 @@ def load_prompt_learner_state(directory: str, epoch: Optional[int] = None) -> Di
         if k in ("token_prefix", "token_suffix"):                                 # :482-487
             continue
         out[k] = v
-    return out
+    return out, (ckpt.get("epoch") if isinstance(ckpt, dict) else None), path
+
+
+def load_prompt_learner_state(directory: str, epoch: Optional[int] = None) -> Dict[str, torch.Tensor]:
+    return load_prompt_learner_checkpoint(directory, epoch)[0]
 
 
 def save_prompt_learner_state(state_dict: Dict[str, torch.Tensor], directory: str, epoch: int,

@@ -196,7 +196,9 @@ __global__ __launch_bounds__(128) void attn_f32_small(const float* __restrict__ 
 int launch_attention_f16_v1(const half_t* qkv, half_t* out, int B, int L, int Lq, int H, int causal, hipStream_t s);  // attention_v1.hip
 
 int launch_attention_f16_v3(const half_t* qkv, half_t* out, int B, int L, int Lq, int H, int causal, hipStream_t s);  // attention_v3.hip
+#ifdef OVMR_EXPERIMENTS
 int launch_attention_f16_v4(const half_t* qkv, half_t* out, int B, int L, int Lq, int H, int causal, int mode, hipStream_t s);  // attention_v4.hip
+#endif
 
 int launch_attention_f16(const half_t* qkv, half_t* out, int B, int L, int H, int causal, int variant, hipStream_t s) {
     return launch_attention_f16_q(qkv, out, B, L, L, H, causal, variant, s);
@@ -205,11 +207,16 @@ int launch_attention_f16(const half_t* qkv, half_t* out, int B, int L, int H, in
 int launch_attention_f16_q(const half_t* qkv, half_t* out, int B, int L, int Lq, int H, int causal, int variant, hipStream_t s) {
     if (B <= 0 || L <= 0 || Lq <= 0) return 0;
     if (Lq > L) return -2;
-    if (variant == 4 || (variant >= 400 && variant < 1000)) {   // single pass, free-running waves (flags instead of a barrier); 400 + mode: timing-only ablations of experiment builds
+#ifdef OVMR_EXPERIMENTS   // variant 4: variant 3's arithmetic with free-running producer / consumer waves (LDS flags instead of the barrier),
+    // the vehicle of the r02 ablations (400 + mode: timing-only); same speed as 3, so only the experiment build carries it
+    if (variant == 4 || (variant >= 400 && variant < 1000)) {
         const int rc = launch_attention_f16_v4(qkv, out, B, L, Lq, H, causal, variant == 4 ? 0 : variant - 400, s);
         if (rc != -100) return rc;
         variant = 1;
     }
+#else
+    if (variant == 4) variant = 3;
+#endif
     if (variant == 3) {               // single-pass kernel for the ViT-B/16 image shape; everything else as variant 1
         const int rc = launch_attention_f16_v3(qkv, out, B, L, Lq, H, causal, s);
         if (rc != -100) return rc;

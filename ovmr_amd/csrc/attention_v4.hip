@@ -19,6 +19,8 @@
 //     head that has lived in it.  No s_barrier after the flags are initialised.
 // The per-tile arithmetic is variant 3's: 26 MFMAs for the S^T row block, exact row maximum, 52 exponentials, P^T packed into the
 // B operands of 7 PV steps, row sums from the matrix pipe.
+// Compiled into the EXPERIMENT build only (python -m ovmr_amd.build --experiments): same speed as variant 3, kept as the vehicle of the ablations.
+#ifdef OVMR_EXPERIMENTS
 #include "attn_single_pass.h"
 
 #include <algorithm>
@@ -195,3 +197,5 @@ int launch_attention_f16_v4(const half_t* qkv, half_t* out, int B, int L, int Lq
     if (mode != 0) return -5;
     return launch_v4_mode<0>(qkv, out, B, L, H, s);
 }
+
+#endif  // OVMR_EXPERIMENTS

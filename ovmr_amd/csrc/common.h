@@ -56,6 +56,7 @@ struct GemmArgs {
     float* stats_out;                      // EPI_BIAS_RES, optional: partial statistics of the stored C rows, [M][N/256][2]
     int nt_store;                          // v5: 0 = auto (streaming stores when C is much larger than the L2s), 1 = never, 2 = always
     float* argmax_out;                     // EPI_SCALE_ARGMAX: [M][ceil(N/256)][2] (value, column index bits)
+    int gelu_mode;                         // QuickGELU epilogues: 0 = the reference's three fp16 rounding points, 1 = quick_gelu_f32x2 (set from variant / 100)
 };
 
 __device__ __forceinline__ float quick_gelu_h(float u) {
@@ -109,6 +110,23 @@ __device__ __forceinline__ half4_t quick_gelu_h4(half4_t u) {
     const float2_t sp = q * rr, sq = p * rr;                       // (1/a, 1/c), (1/b, 1/d)
     const half4_t s = __builtin_convertvector((float4_t){sp[0], sq[0], sp[1], sq[1]}, half4_t);
     return u * s;
+}
+
+// QuickGELU with ONE rounding point instead of the reference's three (ovmr_set_option "gelu_exact" = 0): the GEMM epilogue calls
+// this on the fp32 value x = acc + bias BEFORE it is rounded to fp16 and rounds the product once, g = h(x / (1 + 2^(-1.702 log2(e) x)))
+// -- v_mul_f32, v_exp_f32, v_add_f32, v_rcp_f32, v_mul_f32 at the full fp32 rate plus half a v_cvt_pk_f16_f32 per element, where
+// quick_gelu_h4 takes a quarter-rate v_fma_mixlo_f16, 1.25 transcendentals and 5 more instructions (profiles/r03a_valu_rate.log: per SIMD
+// with two waves, v_fma/mul/add_f32 2.6 cycles, other VOP3 4.4, transcendentals / v_fma_mixlo_f16 / v_permlane16_swap 8.3).  It is
+// CLOSER to the real function than the reference's fp16 form (no h(u), h(1.702 u), h(sigmoid) in between); against the reference's
+// result it differs by at most a few fp16 steps of the result (bound stated in tests/test_hip_kernels.py).  x < -52: e = +inf, s = 0, g = -0.
+__device__ __forceinline__ float2_t quick_gelu_f32x2(float2_t x) {
+    float2_t g;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const float e = __builtin_amdgcn_exp2f(x[k] * -2.4554669595930157f);
+        g[k] = x[k] * __builtin_amdgcn_rcpf(1.0f + e);
+    }
+    return g;
 }
 
 __device__ __forceinline__ float wave_sum(float v) {

@@ -30,9 +30,14 @@ __device__ __forceinline__ void epilogue_store(const GemmArgs& a, int m, int n, 
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         float x = acc[r];
-        if (EPI == EPI_BIAS || EPI == EPI_BIAS_QGELU || EPI == EPI_BIAS_RES) x = (float)(half_t)(x + bias[r]);
-        else x = (float)(half_t)x;
-        if (EPI == EPI_BIAS_QGELU) x = quick_gelu_h(x);
+        if (EPI == EPI_BIAS_QGELU && a.gelu_mode) {          // the one-rounding form (common.h quick_gelu_f32x2), as the 256-row kernels
+            const float xb = x + bias[r];
+            x = (float)(half_t)(xb * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(xb * -2.4554669595930157f)));
+        } else {
+            if (EPI == EPI_BIAS || EPI == EPI_BIAS_QGELU || EPI == EPI_BIAS_RES) x = (float)(half_t)(x + bias[r]);
+            else x = (float)(half_t)x;
+            if (EPI == EPI_BIAS_QGELU) x = quick_gelu_h(x);
+        }
         if (EPI == EPI_SCALE) x = x * a.scale;
         v[r] = x;
     }

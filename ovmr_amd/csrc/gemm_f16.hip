@@ -133,7 +133,12 @@ int launch_gemm_f16_v5(const GemmArgs& a, int variant, hipStream_t s);  // gemm_
 // variant 0: the 128x128 register-staged kernel above for every shape; 6: 256-row tiles with the double-buffered K loop;
 // 8 (default): 6 with the ping-pong K loop.  6 / 8 fall back to the 128x128 kernel for shapes they do not take
 // (M < 256, N < 128, ...).  Experiment builds (OVMR_EXPERIMENTS) add timing-only ablation variants (gemm_f16_v5.hip).
-int launch_gemm_f16(const GemmArgs& a, int variant, hipStream_t s) {
+int launch_gemm_f16(const GemmArgs& a_in, int variant, hipStream_t s) {
+    GemmArgs a = a_in;
+    if (variant >= 100) {                   // variant = kernel + 100 * QuickGELU form (common.h quick_gelu_fast_h4)
+        a.gelu_mode = variant / 100;
+        variant %= 100;
+    }
     if (a.M <= 0 || a.N <= 0) return 0;
     if (a.K <= 0 || (a.K % BK) != 0 || (a.lda & 7) || (a.ldw & 7)) return -2;  // caller pads K to 64
     const int v5 = variant == 0 ? 8 : variant;

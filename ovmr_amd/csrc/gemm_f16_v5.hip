@@ -57,8 +57,9 @@ __global__ __launch_bounds__(512) void gemm_f16_v5_kernel(GemmArgs a, int tiles_
     constexpr int BM = MT * 32;
     constexpr int A_BYTES = BM * 128, STAGE = (BM + BN5) * 128;
     constexpr int AJ = BM / 64;
-    constexpr int EP = 144;                            // epilogue LDS row pitch (64 halves + 16 B pad)
     constexpr bool NOSTORE = OPT & 64, NOEPI = OPT & 128, NT = OPT & 512;
+    constexpr int EP = 128;                            // epilogue staging tile: 128-byte rows, swizzled 8-byte units (below)
+    constexpr bool GFAST = (OPT & 2048) != 0;          // QuickGELU: the one-rounding fp32 form (common.h quick_gelu_f32x2) instead of the reference's three fp16 rounding points
     constexpr bool LNF = EPI == EPI_LN_BIAS || EPI == EPI_LN_BIAS_QGELU;   // LayerNorm folded into this GEMM (common.h)
     constexpr bool HAS_BIAS = EPI == EPI_BIAS || EPI == EPI_BIAS_QGELU || EPI == EPI_BIAS_RES;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -518,6 +519,24 @@ __global__ __launch_bounds__(512) void gemm_f16_v5_kernel(GemmArgs a, int tiles_
     };
     char* et = smem + wave * (64 * EP);                 // this wave's 64-row x 64-column staging tile
     const int er = lane >> 3, ec = (lane & 7) * 8;     // phase 2: row within an 8-row group, first column
+    // The staging tile has 128-byte rows of sixteen 8-byte units; unit u of row r is stored at u ^ f(r & 15),
+    // f(r) = ((r & 7) << 1) | (r >> 3): the 16-byte chunk index is XORed with r & 7 (the K loop's swizzle) and the two halves of
+    // a chunk trade places in rows 8..15.  Phase 1 (8-byte writes, 16 lanes = the 16 rows of one unit column, 32 banks): f is a
+    // bijection, 16 different units = all 32 banks.  Phase 2 reads whole chunks (ds_read_b128, four lanes each of four rows per
+    // group, 64 banks): the chunk XOR keeps the two rows that share a bank half on different chunks, and whether a lane's chunk
+    // arrives with its halves exchanged is a compile-time fact (rows it*8 + er: odd it), so putting them back costs nothing.
+    // SQ_LDS_BANK_CONFLICT = 0 (profiles/r03b_pmc_gemm_v109.json); the 144-byte padded rows this replaces were 2-way on every
+    // write and on one read group in four (r02o: 11.7 % of the LDS cycles) -- at equal run time (r03c: -0.3 ... +0.8 %).
+    const int fsw = ((fr & 7) << 1) | (fr >> 3);
+    int wr_off[4];                                      // phase 1: byte offset of column block j inside this lane's row fr
+#pragma unroll
+    for (int j = 0; j < 4; ++j) wr_off[j] = fr * EP + (((j * 4 + fg) ^ fsw) << 3);
+    const int rd_off = er * EP + (((lane & 7) ^ er) << 4);
+    auto read_staged = [&](int it) -> half8_t {         // rows it*8 + er, this lane's eight columns
+        const half8_t v = *(const half8_t*)(et + it * 8 * EP + rd_off);
+        if (it & 1) return (half8_t){v[4], v[5], v[6], v[7], v[0], v[1], v[2], v[3]};
+        return v;
+    };
     const bool emit_stats = EPI == EPI_BIAS_RES && a.stats_out != nullptr;
     const bool full_tile = EPI != EPI_PATCH && m0 + BM <= a.M && n0 + BN5 <= a.N;   // workgroup-uniform
     float* stat_lds = (float*)(smem + 8 * 64 * EP);      // [BM rows][4 column waves][2], behind the staging tiles
@@ -569,12 +588,13 @@ __global__ __launch_bounds__(512) void gemm_f16_v5_kernel(GemmArgs a, int tiles_
                     for (int r = 0; r < 4; r += 2) {
                         // two columns per instruction (v_pk_fma_f32): same two fused multiply-adds per element as the scalar form
                         const float2_t t2 = __builtin_elementwise_fma((float2_t){ln_t, ln_t}, (float2_t){c0[r], c0[r + 1]}, (float2_t){c1[r], c1[r + 1]});
-                        const float2_t x2 = __builtin_elementwise_fma((float2_t){ln_r, ln_r}, (float2_t){v[r], v[r + 1]}, t2);
+                        float2_t x2 = __builtin_elementwise_fma((float2_t){ln_r, ln_r}, (float2_t){v[r], v[r + 1]}, t2);
+                        if (EPI == EPI_LN_BIAS_QGELU && GFAST) x2 = quick_gelu_f32x2(x2);
                         const half2_t u2 = __builtin_convertvector(x2, half2_t);
                         o[r] = u2[0];
                         o[r + 1] = u2[1];
                     }
-                    if (EPI == EPI_LN_BIAS_QGELU) o = gelu4(o);
+                    if (EPI == EPI_LN_BIAS_QGELU && !GFAST) o = gelu4(o);
                 } else {
                     // float2 sums and __builtin_convertvector: v_pk_add_f32 + v_cvt_pk_f16_f32 (round to nearest even), two
                     // elements per instruction; element-wise casts made hipcc emit cvt + pack + alignbit chains (3.8 -> ~1.6
@@ -583,6 +603,7 @@ __global__ __launch_bounds__(512) void gemm_f16_v5_kernel(GemmArgs a, int tiles_
                     for (int r = 0; r < 4; r += 2) {
                         float2_t x2 = {v[r], v[r + 1]};
                         if (HAS_BIAS) x2 += (float2_t){c0[r], c0[r + 1]};
+                        if (EPI == EPI_BIAS_QGELU && GFAST) x2 = quick_gelu_f32x2(x2);
                         half2_t u2 = __builtin_convertvector(x2, half2_t);
                         if (EPI == EPI_SCALE) {                                   // h(h(acc) * scale)
                             float2_t y2 = __builtin_convertvector(u2, float2_t);
@@ -592,9 +613,9 @@ __global__ __launch_bounds__(512) void gemm_f16_v5_kernel(GemmArgs a, int tiles_
                         o[r] = u2[0];
                         o[r + 1] = u2[1];
                     }
-                    if (EPI == EPI_BIAS_QGELU) o = gelu4(o);
+                    if (EPI == EPI_BIAS_QGELU && !GFAST) o = gelu4(o);
                 }
-                *(half4_t*)(et + (i * 16 + fr) * EP + (j * 16 + fg * 4) * 2) = o;
+                *(half4_t*)(et + i * 16 * EP + wr_off[j]) = o;
             }
         }
         const int nn = n0 + wn * 64 + ec;
@@ -629,7 +650,7 @@ __global__ __launch_bounds__(512) void gemm_f16_v5_kernel(GemmArgs a, int tiles_
             // walk one pointer; the guarded loop below costs 13 instructions and one exposed LDS round trip per store
             half8_t vv[8];
 #pragma unroll
-            for (int it = 0; it < 8; ++it) vv[it] = *(const half8_t*)(et + (it * 8 + er) * EP + ec * 2);
+            for (int it = 0; it < 8; ++it) vv[it] = read_staged(it);
             half_t* dst = C + (long)(m0 + wm * (BM / 2) + h * 64 + er) * a.ldc + nn;
             const long step = 8L * a.ldc;
 #pragma unroll
@@ -644,7 +665,7 @@ __global__ __launch_bounds__(512) void gemm_f16_v5_kernel(GemmArgs a, int tiles_
                 const int row = it * 8 + er;
                 const int m = m0 + wm * (BM / 2) + h * 64 + row;
                 if (m < a.M && nn < a.N) {                  // N % 8 == 0 is guaranteed by the launcher
-                    half8_t v = finish(*(const half8_t*)(et + row * EP + ec * 2), it, row);
+                    half8_t v = finish(read_staged(it), it, row);
                     long crow = m;
                     if (EPI == EPI_PATCH) {
                         const int b = m / a.rows_in, p = m - b * a.rows_in;
@@ -710,16 +731,17 @@ int launch_v5(const GemmArgs& a, hipStream_t s) {
         static const int force = exp_env("OVMR_NT_STORE");
         b.nt_store = force ? force : (b.epi != EPI_BIAS_RES && (size_t)b.M * b.N * 2 >= ((size_t)48 << 20) ? 2 : 1);
     }
-    constexpr int P8 = OPT & (16 | 32);                 // (32: experiment bit, rides along) ping-pong K loop (256-row tiles; it replaces the OPT & 4 loop there)
-    constexpr bool PLAIN = (OPT & ~(16 | 32)) == 0;
+    constexpr int XB = OPT & 2048;                      // QuickGELU form: carried into every K-loop choice below
+    constexpr int P8 = OPT & (16 | 32 | XB);            // (32: experiment bit, rides along) ping-pong K loop (256-row tiles; it replaces the OPT & 4 loop there)
+    constexpr bool PLAIN = (OPT & ~(16 | 32 | XB)) == 0;
     constexpr bool OV_OK = !((OPT & 16) && MT == 8);
     if constexpr (PLAIN && OV_OK && (EPI == EPI_LN_BIAS || EPI == EPI_LN_BIAS_QGELU)) {
         // the LayerNorm-folding launches also run the K loop with the boundary inside the MFMA stream (qkv_ln 354 -> 343 us,
         // c_fc_ln 525 -> 518 us; the plain bias / QuickGELU launches of the same shapes do not gain)
         static const int ov_force = exp_env("OVMR_K_OVERLAP");
         if (ov_force != 1) {
-            if (b.nt_store == 2) return launch_v5_k<EPI, MT, 4 | 512>(b, tiles_m, tiles_n, s);
-            return launch_v5_k<EPI, MT, 4>(b, tiles_m, tiles_n, s);
+            if (b.nt_store == 2) return launch_v5_k<EPI, MT, XB | 4 | 512>(b, tiles_m, tiles_n, s);
+            return launch_v5_k<EPI, MT, XB | 4>(b, tiles_m, tiles_n, s);
         }
     }
     if constexpr (PLAIN && EPI != EPI_BIAS_RES) {
@@ -742,8 +764,8 @@ int launch_v5(const GemmArgs& a, hipStream_t s) {
         static const int a_nt_force = exp_env("OVMR_A_NT"), ov_force = exp_env("OVMR_K_OVERLAP");   // 1 = never, 2 = always
         const bool a_nt = a_nt_force != 1 && (a_nt_force == 2 || (tiles_n <= 4 && tiles_m * tiles_n >= 512));
         const bool ov = OV_OK && ov_force != 1 && (ov_force == 2 || b.K >= 2048);
-        if (a_nt && ov) return launch_v5_k<EPI, MT, 5>(b, tiles_m, tiles_n, s);
-        if (ov) return launch_v5_k<EPI, MT, 4>(b, tiles_m, tiles_n, s);
+        if (a_nt && ov) return launch_v5_k<EPI, MT, XB | 5>(b, tiles_m, tiles_n, s);
+        if (ov) return launch_v5_k<EPI, MT, XB | 4>(b, tiles_m, tiles_n, s);
         if (a_nt) return launch_v5_k<EPI, MT, P8 | 1>(b, tiles_m, tiles_n, s);
     }
     return launch_v5_k<EPI, MT, OPT>(b, tiles_m, tiles_n, s);
@@ -777,17 +799,22 @@ int pick_v5(const GemmArgs& a, hipStream_t s) {
     return big ? launch_v5<EPI, 8, OPT>(a, s) : launch_v5<EPI, 4, OPT>(a, s);
 }
 
+template <int EPI, int OPT>
+int pick_gelu(const GemmArgs& a, hipStream_t s) {      // QuickGELU form (GemmArgs::gelu_mode) -> template bit 2048
+    return a.gelu_mode ? pick_v5<EPI, OPT | 2048>(a, s) : pick_v5<EPI, OPT>(a, s);
+}
+
 template <int OPT>
 int dispatch_v5(const GemmArgs& a, hipStream_t s) {
     switch (a.epi) {
         case EPI_NONE: return pick_v5<EPI_NONE, OPT>(a, s);
         case EPI_BIAS: return pick_v5<EPI_BIAS, OPT>(a, s);
-        case EPI_BIAS_QGELU: return pick_v5<EPI_BIAS_QGELU, OPT>(a, s);
+        case EPI_BIAS_QGELU: return pick_gelu<EPI_BIAS_QGELU, OPT>(a, s);
         case EPI_BIAS_RES: return pick_v5<EPI_BIAS_RES, OPT>(a, s);
         case EPI_PATCH: return pick_v5<EPI_PATCH, OPT>(a, s);
         case EPI_SCALE: return pick_v5<EPI_SCALE, OPT>(a, s);
         case EPI_LN_BIAS: return pick_v5<EPI_LN_BIAS, OPT>(a, s);
-        case EPI_LN_BIAS_QGELU: return pick_v5<EPI_LN_BIAS_QGELU, OPT>(a, s);
+        case EPI_LN_BIAS_QGELU: return pick_gelu<EPI_LN_BIAS_QGELU, OPT>(a, s);
         case EPI_SCALE_ARGMAX: return pick_v5<EPI_SCALE_ARGMAX, OPT>(a, s);
     }
     return -3;

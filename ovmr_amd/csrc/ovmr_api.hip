@@ -40,6 +40,7 @@ struct ovmr_handle {
     std::vector<void*> derived;   // layouts rebuilt by every ovmr_finalize
     std::string err;
     bool finalized = false;
+    int gelu_exact = 0;                       // 0: one-rounding fp32 QuickGELU in the c_fc epilogue (common.h quick_gelu_f32x2); 1: the reference's three fp16 rounding points
     int gemm_variant = 8, attn_variant = 3;   // defaults = fastest verified kernels (tools/gemm_bench.py, tools/attn_bench.py); attention 3 falls back to 1 / 0 by shape
     int ln_fold = 1;                          // fold ln_1 / ln_2 of the fp16 towers into the consuming GEMM where the shape allows
     int xval_fused = 1;                       // cross-validation logits: row argmax fused into the GEMM epilogue (never stored)
@@ -198,10 +199,10 @@ int run_block_f16(ovmr_handle* h, const Block& k, half_t* x, half_t* y, half_t* 
     CK(launch_attention_f16(qkv, y, nseq, L, H, causal, h->attn_variant, s));
     CK(launch_gemm_f16(gemm_stats(gemm(y, W, k.out_w, W, x, W, M, W, W, EPI_BIAS_RES, k.out_b, x, W), stats), h->gemm_variant, s));
     if (stats) {
-        CK(launch_gemm_f16(gemm_ln(gemm(x, W, k.fc_wf, W, hid, 4 * W, M, 4 * W, W, EPI_LN_BIAS_QGELU), stats, slots, k.fc_g, k.fc_bf), h->gemm_variant, s));
+        CK(launch_gemm_f16(gemm_ln(gemm(x, W, k.fc_wf, W, hid, 4 * W, M, 4 * W, W, EPI_LN_BIAS_QGELU), stats, slots, k.fc_g, k.fc_bf), h->gemm_variant + (h->gelu_exact ? 0 : 100), s));
     } else {
         CK(launch_layernorm(x, y, k.ln2_g, k.ln2_b, M, W, W, 0, s));
-        CK(launch_gemm_f16(gemm(y, W, k.fc_w, W, hid, 4 * W, M, 4 * W, W, EPI_BIAS_QGELU, k.fc_b), h->gemm_variant, s));
+        CK(launch_gemm_f16(gemm(y, W, k.fc_w, W, hid, 4 * W, M, 4 * W, W, EPI_BIAS_QGELU, k.fc_b), h->gemm_variant + (h->gelu_exact ? 0 : 100), s));
     }
     CK(launch_gemm_f16(gemm_stats(gemm(hid, 4 * W, k.pj_w, 4 * W, x, W, M, W, 4 * W, EPI_BIAS_RES, k.pj_b, x, W), stats), h->gemm_variant, s));
     return 0;
@@ -275,6 +276,7 @@ int ovmr_set_option(ovmr_handle* h, const char* key, int value) {
     else if (!strcmp(key, "attn")) h->attn_variant = value;
     else if (!strcmp(key, "ln_fold")) h->ln_fold = value;
     else if (!strcmp(key, "xval_fused")) h->xval_fused = value;
+    else if (!strcmp(key, "gelu_exact")) h->gelu_exact = value;
     else return fail(h, OVMR_E_NAME, "unknown option '%s'", key);
     return 0;
 }
@@ -464,7 +466,7 @@ int ovmr_encode_image(ovmr_handle* h, const void* image, int image_dtype, int B,
             CK(launch_attention_f16_q(qkv, yc, Bc, L, 1, H, 0, h->attn_variant, s));
             CK(launch_gemm_f16(gemm(yc, W, k.out_w, W, rows, W, Bc, W, W, EPI_BIAS_RES, k.out_b, x, L * W), h->gemm_variant, s));
             CK(launch_layernorm(rows, yc, k.ln2_g, k.ln2_b, Bc, W, W, 0, s));
-            CK(launch_gemm_f16(gemm(yc, W, k.fc_w, W, hid_c, 4 * W, Bc, 4 * W, W, EPI_BIAS_QGELU, k.fc_b), h->gemm_variant, s));
+            CK(launch_gemm_f16(gemm(yc, W, k.fc_w, W, hid_c, 4 * W, Bc, 4 * W, W, EPI_BIAS_QGELU, k.fc_b), h->gemm_variant + (h->gelu_exact ? 0 : 100), s));
             CK(launch_gemm_f16(gemm(hid_c, 4 * W, k.pj_w, 4 * W, rows, W, Bc, W, 4 * W, EPI_BIAS_RES, k.pj_b, rows, W), h->gemm_variant, s));
         }
         // K9: ln_post on the CLS rows, projection; K10: normalise

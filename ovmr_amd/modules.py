@@ -268,10 +268,18 @@ class CustomCLIP:
     """trainers/mm_classifier_one_prompt.py:179-364 (evaluation / classifier-generation branch)."""
 
     def __init__(self, cfg, classnames, clip_model: CLIPModel, tokenizer=None,
-                 prompt_learner_state: Optional[Dict] = None, reserve=None):
+                 prompt_learner_state: Optional[Dict] = None, reserve=None, distributed: Optional[bool] = None):
+        """distributed: None = shard over the default process group when it has more than one rank; True = take the sharded
+        path whenever a process group is initialised (also with ONE rank: the collectives then run through the backend --
+        RCCL for "nccl" -- on this rank's own rows, tests/test_hip_distributed.py); False = never."""
         self.cfg = cfg
         import torch.distributed as dist
-        self._dist = dist if (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1) else None
+        ready = dist.is_available() and dist.is_initialized()
+        if distributed is None:
+            distributed = ready and dist.get_world_size() > 1
+        if distributed and not ready:
+            raise RuntimeError("CustomCLIP(distributed=True) needs an initialised torch.distributed process group")
+        self._dist = dist if distributed else None
         if reserve is None:
             reserve = (cfg.DATALOADER.TEST.BATCH_SIZE if hasattr(cfg.DATALOADER, "TEST") else 256, 256, 1024)
         self.prompt_learner = PromptLearner(cfg, classnames, clip_model, tokenizer, prompt_learner_state,
@@ -335,7 +343,13 @@ class CustomCLIP:
         text_clf = torch.zeros((C, D), **f16) if streamed_text else self.zero_shot_classifier
         local_labels = []
         presharded = bool(getattr(eval_set_loader, "presharded", False))
+        cpb = max(1, self.cfg.DATALOADER.TEST.BATCH_SIZE // S)
         for batch_idx, batch in enumerate(eval_set_loader):
+            if dist and not presharded and batch["label"].shape[0] // S > cpb:
+                # every rank iterates over every batch of a round-robin loader, so every rank raises HERE, before any of them
+                # has entered the all-gather whose block size assumes at most `cpb` classes per batch (shard.local_class_bound)
+                raise RuntimeError(f"eval-set batch {batch_idx} holds {batch['label'].shape[0] // S} classes, more than "
+                                   f"TEST.BATCH_SIZE // NUM_SHOTS = {cpb}")
             if not presharded and batch_idx % world != rank:
                 continue
             image = self._batch_images(batch, dev)
@@ -360,7 +374,7 @@ class CustomCLIP:
             from .shard import all_gather_rows, local_class_bound
             packed = torch.cat([self.mm_classifier[local], self.visual_classifer[local], text_clf[local],
                                 self.visual_tokens[local].flatten(1)], dim=1)
-            bound = local_class_bound(C, world, presharded, max(1, self.cfg.DATALOADER.TEST.BATCH_SIZE // S))
+            bound = local_class_bound(C, world, presharded, cpb)
             rows, labels = all_gather_rows(packed, local, bound, dist)
             full = torch.zeros((C + 1, rows.shape[1]), **f16)                       # row C collects the padding rows
             full.index_copy_(0, torch.where(labels >= 0, labels, C).long(), rows)

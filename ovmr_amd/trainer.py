@@ -70,7 +70,7 @@ class MM_CLS_OP:
         self.model = modules.CustomCLIP(cfg, classnames, clip_model, tokenizer=self._tokenizer)
         init = getattr(cfg.MODEL, "INIT_WEIGHTS", "")
         if init:                                                              # load_pretrained_weights (:403-404)
-            ckpt = torch.load(init, map_location="cpu", weights_only=False)
+            ckpt = checkpoint._torch_load(init)
             self.model.prompt_learner.load_state_dict(ckpt["state_dict"] if "state_dict" in ckpt else ckpt, strict=False)
         self.register_model("prompt_learner", self.model.prompt_learner)     # :410
 
@@ -87,26 +87,15 @@ class MM_CLS_OP:
     def parse_batch_test(self, batch):
         return batch["img"].to(self.device), batch["label"].to(self.device)
 
-    # :461-493
+    # :461-493 -- the file handling lives in ovmr_amd.checkpoint (Dassl layout, "module." prefixes, dropped token buffers)
     def load_model(self, directory, epoch=None):
         if not directory:
             print("Note that load_model() is skipped as no pretrained model is given")
             return
-        names = self.get_model_names()
-        model_file = "model-best.pth.tar"                                    # by default, the best model is loaded
-        if epoch is not None:
-            model_file = "model.pth.tar-" + str(epoch)
-        for name in names:
-            model_path = osp.join(directory, name, model_file)
-            if not osp.exists(model_path):
-                raise FileNotFoundError('Model not found at "{}"'.format(model_path))
-            ckpt = torch.load(model_path, map_location="cpu", weights_only=False)
-            state_dict = dict(ckpt["state_dict"])
-            ep = ckpt["epoch"]
-            state_dict.pop("token_prefix", None)                              # ignore fixed token vectors (:482-487)
-            state_dict.pop("token_suffix", None)
-            print("Loading weights to {} " 'from "{}" (epoch = {})'.format(name, model_path, ep))
-            self._models[name].load_state_dict(state_dict, strict=False)     # :493
+        for name in self.get_model_names():
+            state, saved_epoch, path = checkpoint.load_prompt_learner_checkpoint(directory, epoch, name)
+            print(f'Loading weights to {name} from "{path}" (epoch = {saved_epoch})')
+            self._models[name].load_state_dict(state, strict=False)
 
     # trainer.py:504-508
     def model_inference(self, input, scale_no=0, label=None):

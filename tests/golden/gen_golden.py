@@ -253,7 +253,7 @@ def aligned_inputs(spec, C, shots, n_query, strength, tile):
 
 @torch.no_grad()
 def gen_l2_aligned(ref_model, ref_l2, spec, seed, gain, out, tag="l2a", C=12, shots=8, cpb=4, n_query=8,
-                   strength=0.9, tile=16, tau=3.0, n_ctx=2):
+                   strength=0.9, tile=16, tau=3.0, n_ctx=2, strict=True):
     sd_np = synth.clip_state_dict(spec, seed, jitter=True)
     pl_np = synth.prompt_learner_state_dict(spec, n_ctx, seed, True)
     synth.align_state_dicts(sd_np, pl_np, spec, gain)
@@ -311,12 +311,13 @@ def gen_l2_aligned(ref_model, ref_l2, spec, seed, gain, out, tag="l2a", C=12, sh
         margin = srt[:, -1] - srt[:, -2]
         acc = float((l3.argmax(1) == np.repeat(np.arange(C), shots)).mean())
         stats[k] = (float(margin.min()), acc)
-        assert margin.min() > MARGIN, f"{tag} {k}: top-2 margin {margin.min():.3f} <= {MARGIN}"
+        assert not strict or margin.min() > MARGIN, f"{tag} {k}: top-2 margin {margin.min():.3f} <= {MARGIN}"
     qm = {}
     for mode, k in (("multimodal", "mm_classifier"), ("vision", "vision_classifier"), ("text", "text_classifier")):
         qf = out[f"{tag}_logits_{mode}"]
         qm[mode] = float(np.sort(qf, axis=1)[:, -1].min())
     print(f"{tag} {spec.name}: names {names}\n   (min margin, accuracy) {stats}\n   fusion_weight\n{np.round(out[tag + '_saved_fusion_weight'], 3)}")
+    return stats
 
 
 def gen_tokenizer(ref_clip, out):

@@ -19,12 +19,12 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _launch(world, result, presharded, C):
+def _launch(world, result, presharded, C, backend="gloo"):
     port = _free_port()
     procs = []
     for rank in range(world):
         env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   HSA_ENABLE_IPC_MODE_LEGACY="0")
+                   HSA_ENABLE_IPC_MODE_LEGACY="0", OVMR_TEST_BACKEND=backend)
         procs.append(subprocess.Popen([sys.executable, WORKER, result, str(presharded), str(C)], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     outs = [p.communicate(timeout=600)[0] for p in procs]
@@ -43,3 +43,20 @@ def test_multi_process_generation_bit_equal_to_single_process(tmp_path):
         for k in ("mm", "v", "t", "tokens", "counts", "w", "out"):
             assert torch.equal(single[k], got[k]), f"world {world} presharded {presharded}: {k} differs"
         assert got["files"] == ["mm_classifiers.pt", "visual_tokens.pt"]          # rank 0 wrote the files
+
+
+@pytest.mark.timeout(900)
+def test_rccl_collectives_with_one_rank_bit_equal(tmp_path):
+    """The `nccl` (= RCCL) branch on the hardware a test box has: ONE rank, process group "nccl" bound to cuda:0, the sharded
+    path forced with CustomCLIP(distributed=True).  The packed all-gather and the counter all-reduce then run on DEVICE tensors
+    through librccl (no host staging, shard._staged is the identity for this backend) and must leave rows, counters, fusion
+    weights and outputs bit-equal to the run without a process group -- for the round-robin and for the class-sharded loader."""
+    C = 7
+    single = _launch(1, str(tmp_path / "w1.pt"), 0, C)
+    assert single["backend"] == "none" and not single["sharded_path"]
+    for presharded in (0, 1):
+        got = _launch(1, str(tmp_path / f"rccl_{presharded}.pt"), presharded, C, backend="nccl")
+        assert got["backend"] == "nccl" and got["sharded_path"] and got["rccl_loaded"]
+        for k in ("mm", "v", "t", "tokens", "counts", "w", "out"):
+            assert torch.equal(single[k], got[k]), f"nccl world 1, presharded {presharded}: {k} differs"
+        assert got["files"] == ["mm_classifiers.pt", "visual_tokens.pt"]

@@ -11,7 +11,7 @@ pytestmark = pytest.mark.gpu
 
 EPI_NONE, EPI_BIAS, EPI_BIAS_QGELU, EPI_BIAS_RES, EPI_PATCH, EPI_SCALE = range(6)
 GEMM_VARIANTS = [0, 6, 8]       # 0: 128x128 register-staged; 6 / 8: 256-row LDS-DMA tiles (double-buffered / ping-pong K loop)
-ATTN_VARIANTS = [0, 1, 3, 4]
+ATTN_VARIANTS = [0, 1, 3]        # (variant 4, the barrier-free form of 3, lives in the experiment build only)
 
 
 @pytest.fixture(scope="module")
@@ -202,7 +202,7 @@ def test_attention_f32(lib, B, L, H):
     np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), atol=2e-5, rtol=1e-4)
 
 
-@pytest.mark.parametrize("variant", [6, 8, 0])       # 0: the dispatcher must route LN-folding GEMMs to the v5 kernel itself
+@pytest.mark.parametrize("variant", [6, 8, 0, 108])  # 0: the dispatcher must route LN-folding GEMMs to the v5 kernel itself; 108: 8 with the one-rounding QuickGELU (gelu_exact = 0)
 @pytest.mark.parametrize("M,D,K1,N2,qgelu,produce", [
     (197 * 3, 768, 768, 2304, 0, True), (1000, 768, 3072, 3072, 1, True), (256, 256, 64, 128, 0, True),
     (513, 512, 2048, 1536, 0, True), (300, 1024, 1024, 4096, 1, True), (462, 512, 0, 2048, 1, False),
@@ -262,8 +262,37 @@ def test_gemm_layernorm_fold(lib, variant, M, D, K1, N2, qgelu, produce):
     assert float((1 - cos).max()) < 1e-5
 
 
+@pytest.mark.parametrize("variant", [100, 106, 108])      # kernel + 100: the engine's default QuickGELU form (gelu_exact = 0)
+@pytest.mark.parametrize("M,N,K", [(1000, 3072, 768), (4096, 1024, 768), (130, 256, 128), (197 * 30, 3072, 768)])
+def test_gemm_quickgelu_one_rounding(lib, variant, M, N, K):
+    """The one-rounding QuickGELU of the c_fc epilogue, g = h(x * sigmoid(1.702 x)) evaluated in fp32 on the unrounded x = acc + bias
+    (common.h quick_gelu_f32x2), against the fp64 function: within ONE fp16 step of the result + 2e-5 (the reference's own fp16 form,
+    h(u * h(sigmoid(h(1.702 h(x))))), is up to ~10 steps from the function), and against the reference's fp16 form within the
+    absolute bound 8e-3 * max(1, |g|) -- operands with |x| up to ~8."""
+    g = torch.Generator().manual_seed(M + N + K)
+    A = (torch.randn(M, K, generator=g) * 1.5).half()
+    W = (torch.randn(N, K, generator=g) * K ** -0.5).half()
+    bias = (torch.randn(N, generator=g) * 0.5).half()
+    x = A.double() @ W.double().t() + bias.double()
+    exact = x * torch.sigmoid(1.702 * x)
+    u = _h(x.float())
+    ref16 = _h(u * _h(torch.sigmoid(_h(1.702 * u))))
+    d = "cuda"
+    C = torch.zeros(M, N, dtype=torch.float16, device=d)
+    assert lib.ovmr_debug_gemm(0, variant, _p(A.to(d)), _p(W.to(d)), _p(bias.to(d)), None, None, _p(C), M, N, K, N, EPI_BIAS_QGELU,
+                               1.0, 0, 0, _s()) == 0
+    torch.cuda.synchronize()
+    got = C.float().cpu()
+    assert torch.isfinite(got).all()
+    step = torch.clamp(2.0 ** (torch.floor(torch.log2(exact.abs().clamp_min(2.0 ** -14))) - 10), min=2.0 ** -24)
+    # fp32 accumulation against fp64 moves x itself by up to ~1e-5 in absolute terms (K products of ~0.05): an absolute floor beside
+    # the step, which is what counts around x = 0 where the steps of g = x / 2 shrink to 2^-24
+    assert bool(((got.double() - exact).abs() <= step + 2e-5).all()), float(((got.double() - exact).abs() - step).max())
+    assert float(((got - ref16).abs() / ref16.abs().clamp_min(1.0)).max()) <= 8e-3
+
+
 def test_race_screen_of_hand_synchronised_kernels():
-    """GEMM variant 8 (counted vmcnt across barriers, wave rows one barrier apart) and attention variants 3 / 4 (LDS-DMA from inline
+    """GEMM variant 8 (counted vmcnt across barriers, wave rows one barrier apart) and attention variant 3 (LDS-DMA from inline
     asm, hand-placed waits): repeated launches on fixed inputs, L2 / Infinity Cache thrashed in between, must reproduce the first
     launch bit for bit (tools/race_screen.py; the per-shape comparisons against fp64 statements are the tests above)."""
     import os

@@ -286,12 +286,17 @@ def test_get_fusion_weight_coop_variant(golden, O):
     np.testing.assert_allclose(w.cpu().numpy(), ref.numpy(), atol=1e-5)
 
 
-def test_fusion_head_vs_oracle(O):
+@pytest.mark.parametrize("model,D,cases", [
+    ("tiny", 128, ((6, 4, 5), (37, 3, 9), (1000, 4, 33), (130, 16, 256))),
+    ("ViT-B/16", 512, ((1000, 16, 256),)),     # BASELINE config 3 exactly: 1000 classes x 16 shots, query batch 256, embed_dim 512
+])
+def test_fusion_head_vs_oracle(O, model, D, cases):
     """K18-K21 in isolation on separable synthetic features: counts, F1 -> fusion weights and the four
     EVAL_MODE outputs must match the oracle given IDENTICAL fp16 inputs."""
-    e = _clip("tiny").engine(2)
-    D = 128
-    for C, S, B in ((6, 4, 5), (37, 3, 9), (1000, 4, 33), (130, 16, 256)):
+    e = _clip(model).engine(2)
+    if model != "tiny":
+        e.finalize(64, 64, 1024)
+    for C, S, B in cases:
         g = torch.Generator().manual_seed(C * 31 + S)
         centers = torch.nn.functional.normalize(torch.randn(C, D, generator=g), dim=-1)
         feats = torch.nn.functional.normalize(centers[:, None] + 0.35 * torch.randn(C, S, D, generator=g), dim=-1).half()
@@ -419,8 +424,8 @@ def test_full_size_properties():
 
 
 def test_attention_variants_agree_inside_the_encoder():
-    """ViT-B/16 image features with every attention kernel that takes L = 197 (variants 1, 3, 4) through the whole encoder:
-    variants 3 and 4 share their tile arithmetic and must agree bit for bit; the flash-style variant 1 within fp16 rounding."""
+    """ViT-B/16 image features with both attention kernels that take L = 197 (the single-pass variant 3 and the flash-style
+    variant 1) through the whole encoder: within fp16 rounding of each other."""
     cm = _clip("ViT-B/16")
     e = cm.engine(2)
     e.finalize(64, 64, 256)
@@ -428,12 +433,11 @@ def test_attention_variants_agree_inside_the_encoder():
     img = torch.randn(37, 3, 224, 224, generator=g, device="cuda", dtype=torch.float16)
     f = {}
     try:
-        for v in (3, 4, 1):
+        for v in (3, 1):
             e.set_option("attn", v)
             f[v] = e.encode_image(img, normalize=True).clone()
     finally:
         e.set_option("attn", 3)
-    assert torch.equal(f[3], f[4])
     assert_cosine(f[1].float().cpu().numpy(), f[3].float().cpu().numpy(), 1e-5, "attention variant 1 vs 3")
 
 

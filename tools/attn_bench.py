@@ -4,9 +4,9 @@ import ctypes, json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 # variant 4's timing-only ablations (400 + mode, attention_v4.hip) live in the experiment build only
-_exp = os.path.join(ROOT, "ovmr_amd", "lib", "libovmr_hip_exp.so")
-if os.path.exists(_exp):
-    os.environ.setdefault("OVMR_HIP_LIB", _exp)
+# The product library is timed unless --exp is given (experiment build: ablation variants and A/B switches); the library loaded is printed.
+if "--exp" in sys.argv:
+    os.environ.setdefault("OVMR_HIP_LIB", os.path.join(ROOT, "ovmr_amd", "lib", "libovmr_hip_exp.so"))
 import torch
 from ovmr_amd import runtime
 
@@ -15,9 +15,11 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--only", default="")
 ap.add_argument("--reps", type=int, default=10)
 ap.add_argument("--batch", type=int, default=512, help="images of the image-tower shape")
-ap.add_argument("--variants", type=int, nargs="+", default=[0, 1, 3, 4])
+ap.add_argument("--variants", type=int, nargs="+", default=[0, 1, 3])
+ap.add_argument("--exp", action="store_true", help="time libovmr_hip_exp.so (experiment build: variant 4 and its ablation modes) instead of the product library")
 args = ap.parse_args()
 lib = runtime.load_library()
+print("library:", os.environ.get("OVMR_HIP_LIB", runtime.LIB_PATH), flush=True)
 p = lambda t: ctypes.c_void_p(t.data_ptr())
 s = lambda: ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 for name, B, L, H, causal in (("image", args.batch, 197, 12, 0), ("text", 1000, 10, 8, 1), ("text77", 256, 77, 8, 1), ("vit-l336", 32, 577, 16, 0)):

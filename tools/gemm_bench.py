@@ -12,11 +12,10 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-# the A/B environment switches and the timing-only ablation variants (18 / 19 / 28 / 29) live in the experiment build only:
-#   python -m ovmr_amd.build --experiments
-_exp = os.path.join(ROOT, "ovmr_amd", "lib", "libovmr_hip_exp.so")
-if os.path.exists(_exp):
-    os.environ.setdefault("OVMR_HIP_LIB", _exp)
+# The product library is timed unless --exp is given: the experiment build (python -m ovmr_amd.build --experiments) carries the A/B
+# environment switches and the timing-only ablation variants; the library actually loaded is printed.
+if "--exp" in sys.argv:
+    os.environ.setdefault("OVMR_HIP_LIB", os.path.join(ROOT, "ovmr_amd", "lib", "libovmr_hip_exp.so"))
 import torch
 from ovmr_amd import runtime
 
@@ -29,10 +28,12 @@ def main():
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--zeros", action="store_true", help="zero-filled operands: shows how much of the time is clock/power (cdna guide rule 25)")
     ap.add_argument("--ldpad", type=int, default=0, help="row padding (halves) of A and W: stride experiment")
+    ap.add_argument("--exp", action="store_true", help="time libovmr_hip_exp.so (experiment build) instead of the product library")
     args = ap.parse_args()
     if args.ldpad:
         os.environ["OVMR_DEBUG_LDPAD"] = str(args.ldpad)
     lib = runtime.load_library()
+    print("library:", os.environ.get("OVMR_HIP_LIB", runtime.LIB_PATH), flush=True)
     dev = "cuda"
     M = args.batch * 197
     shapes = [("qkv", M, 2304, 768, 1), ("out_proj", M, 768, 768, 3), ("c_fc", M, 3072, 768, 2), ("c_fc_bias_only", M, 3072, 768, 1), ("n1536_bias", M, 1536, 768, 1), ("c_proj", M, 768, 3072, 3),

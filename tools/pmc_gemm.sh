@@ -1,6 +1,8 @@
 #!/bin/bash
-# PMC passes over the GEMM micro-benchmark (one variant), as MI355X_MICROARCH.md prescribes: counters in their own
-# runs, --kernel-trace only (never with --stats / sys-trace).  Writes <outdir>/summary.json with per-kernel means.
+# PMC passes over the GEMM micro-benchmark (one variant, PRODUCT library), as MI355X_MICROARCH.md prescribes: counters in their
+# own runs, --kernel-trace only (never with --stats / sys-trace).  Writes <outdir>/summary.json with per-kernel means, the derived
+# figures bench.py puts in its roofline object (mfma_busy_frac, hbm_gbps, lds_conflict_frac, clock_ghz) and the hash of the
+# kernel sources they were taken on (ovmr_amd.build.source_sha16: bench.py refuses a summary of other code).
 # usage: tools/pmc_gemm.sh <variant> <outdir> [batch]
 V=${1:-6}; OUT=${2:-gpurun_out/pmc}; B=${3:-512}; R=${GRAFT_REPO_ROOT:-$(pwd)}
 mkdir -p $R/$OUT; cd /tmp; export TMPDIR=/tmp
@@ -11,7 +13,9 @@ run sq1 SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_C
 run sq2 SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_VALU SQ_ACTIVE_INST_VALU
 cd $R
 python3 - <<PY
-import csv, glob, collections, json
+import csv, glob, collections, json, sys
+sys.path.insert(0, ".")
+from ovmr_amd.build import source_sha16
 out = collections.defaultdict(dict)
 for name in ("fetch", "write", "sq1", "sq2"):
     for f in glob.glob("$OUT/%s/**/*counter_collection.csv" % name, recursive=True):
@@ -30,7 +34,14 @@ for key, c in out.items():
     if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
         # gfx950: FETCH_SIZE (KiB) reports half of the bytes of wide coalesced reads -> doubled (MI355X_MICROARCH.md, HBM)
         c["hbm_bytes_per_launch"] = (2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024
-json.dump({"variant": $V, "batch": $B, "kernels": out}, open("$OUT/summary.json", "w"), indent=1)
+        c["hbm_gbps"] = round(c["hbm_bytes_per_launch"] / (c["duration_us_under_pmc"] * 1e-6) / 1e9, 1)
+    if "GRBM_GUI_ACTIVE" in c and "SQ_VALU_MFMA_BUSY_CYCLES" in c:
+        cycles = c["GRBM_GUI_ACTIVE"] / 8.0                        # the counter sums the 8 XCDs (MI355X_MICROARCH.md, DVFS)
+        c["clock_ghz"] = round(cycles / (c["duration_us_under_pmc"] * 1e3), 3)
+        c["mfma_busy_frac"] = round(c["SQ_VALU_MFMA_BUSY_CYCLES"] / (cycles * 1024), 4)   # 256 CUs x 4 matrix pipes
+    if c.get("SQ_LDS_IDX_ACTIVE"):
+        c["lds_conflict_frac"] = round(c.get("SQ_LDS_BANK_CONFLICT", 0.0) / c["SQ_LDS_IDX_ACTIVE"], 4)
+json.dump({"variant": $V, "batch": $B, "kernel_source_sha16": source_sha16(), "kernels": out}, open("$OUT/summary.json", "w"), indent=1)
 for k, c in out.items():
     print(k, c)
 PY
