@@ -96,6 +96,8 @@ __global__ __launch_bounds__(512) void gemm_f16_v5_kernel(GemmArgs a, int tiles_
     }
     const int m0 = tm * BM, n0 = tn * BN5;
 
+    const int nk = a.K / BK5;
+    const int a_step = a.a_blocked ? 16384 : 128, w_step = a.w_blocked ? 16384 : 128;
     const half_t* A = (const half_t*)a.A;
     const half_t* W = (const half_t*)a.W;
 
@@ -103,14 +105,12 @@ __global__ __launch_bounds__(512) void gemm_f16_v5_kernel(GemmArgs a, int tiles_
     const int srow = lane >> 3, slot = lane & 7;
     const int schunk = (slot ^ srow) * 8;
     unsigned oa[AJ], ob[4];                            // byte offsets of this lane's source rows
-    const int nk = a.K / BK5;
     // row-major: row * ld * 2 + chunk, K-tile step 128 B.  blocked [rows/128][K/64][128][64]: one (row block, K-tile)
     // is 16 KiB contiguous, so every LDS-DMA instruction reads 1 KiB of consecutive addresses
     auto src_off = [&](int row, int ld, int blocked) -> unsigned {
         return blocked ? (unsigned)(((long)(row >> 7) * nk) * 16384 + (row & 127) * 128 + schunk * 2)
                        : (unsigned)(((long)row * ld + schunk) * 2);
     };
-    const int a_step = a.a_blocked ? 16384 : 128, w_step = a.w_blocked ? 16384 : 128;
 #pragma unroll
     for (int j = 0; j < AJ; ++j) {
         const int r = m0 + wave * (BM / 8) + j * 8 + srow;

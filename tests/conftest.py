@@ -50,11 +50,14 @@ def near_tie_classes(logits, margin):
     return set(np.nonzero(cand[rows].any(0))[0].tolist())
 
 
-def aligned_case(g, name, tag="l2a", seed=11, n_ctx=2):
-    """Inputs of the `l2a` golden case (tests/golden/gen_golden.py:gen_l2_aligned), regenerated from the fixture's
-    metadata: aligned fp32 state dicts, exemplar images / labels, query images."""
+def aligned_case(g, name, tag="l2a", seed=11, n_ctx=None):
+    """Inputs of an `l2a*` golden case (tests/golden/gen_golden.py:gen_l2_aligned), regenerated from the fixture's
+    metadata: aligned fp32 state dicts, exemplar images / labels, query images.  n_ctx comes from the fixture (2 where an older
+    file does not record it)."""
     from ovmr_amd import synth
     spec = synth.SPECS[name]
+    if n_ctx is None:
+        n_ctx = int(g[f"{tag}_meta_n_ctx"]) if f"{tag}_meta_n_ctx" in g.files else 2
     sd = synth.clip_state_dict(spec, seed, jitter=True)
     pl = synth.prompt_learner_state_dict(spec, n_ctx, seed, True)
     synth.align_state_dicts(sd, pl, spec, float(g[f"{tag}_meta_gain"]))

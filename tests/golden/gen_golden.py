@@ -114,7 +114,13 @@ def build_ref_clip(ref_model, spec, seed, jitter, fp32=False):
     return model.eval()
 
 
-ALIGNED_GAIN = {"small": 3.0, "vitb16": 1.5}     # synth.align_state_dicts gain of the l2a fixtures
+# the aligned (`l2a*`) cases per fixture file: tag -> gen_l2_aligned arguments.  Gain, shots and class count were searched per
+# model (and per n_ctx) for the contract the function asserts: every cross-validation argmax of the reference clear by > MARGIN.
+ALIGNED_CASES = {
+    "tiny": {"l2a": dict(gain=6.0, shots=16, C=6, cpb=3, n_ctx=2), "l2a1": dict(gain=6.0, shots=8, C=6, cpb=3, n_ctx=1)},
+    "small": {"l2a": dict(gain=3.0), "l2a1": dict(gain=5.0, n_ctx=1)},
+    "vitb16": {"l2a": dict(gain=1.5)},
+}
 CLASSNAMES = ["accordion", "bass guitar", "airplane", "sea_horse", "stop sign", "yin yang"]
 
 
@@ -299,7 +305,7 @@ def gen_l2_aligned(ref_model, ref_l2, spec, seed, gain, out, tag="l2a", C=12, sh
         out[f"{tag}_saved_visual_tokens"] = torch.load(os.path.join(outdir, "visual_tokens.pt"))["visual_tokens"].float().numpy()
         out[f"{tag}_eval_feat4cls"] = model.eval_feat4cls.float().numpy()
     for k, v in (("gain", gain), ("shots", shots), ("classes_per_batch", cpb), ("tau", tau), ("strength", strength),
-                 ("tile", tile), ("margin", MARGIN)):
+                 ("tile", tile), ("margin", MARGIN), ("n_ctx", n_ctx)):
         out[f"{tag}_meta_{k}"] = np.array(v)
 
     # the fixture's contract: every argmax of the reference is clear
@@ -357,8 +363,9 @@ def main():
         gen_l2(ref_model, ref_clip, ref_l2, spec, 11, 2, shots, 10.0, cpb, nq, out, "l2")
         if key != "vitb16":
             gen_l2(ref_model, ref_clip, ref_l2, spec, 11, 1, shots, 10.0, cpb, nq, out, "l2n1")
-        if key in ALIGNED_GAIN:
-            gen_l2_aligned(ref_model, ref_l2, spec, 11, ALIGNED_GAIN[key], out)
+        for tag, kw in ALIGNED_CASES.get(key, {}).items():
+            kw = dict(kw)
+            gen_l2_aligned(ref_model, ref_l2, spec, 11, kw.pop("gain"), out, tag=tag, **kw)
         # fp16-valued tensors are stored as float16 (lossless, checked); everything else as produced
         store = {}
         for k, v in out.items():

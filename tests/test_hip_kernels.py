@@ -98,6 +98,7 @@ def test_gemm_f16(lib, variant, M, N, K, epi):
     (4096, 1024, 768, EPI_BIAS_QGELU), (2500, 2304, 768, EPI_BIAS), (5500, 768, 3072, EPI_BIAS_RES), (4096, 1000, 512, EPI_SCALE),
     (30 * 196, 768, 768, EPI_PATCH), (16400, 256, 128, EPI_NONE), (4097, 1280, 640, EPI_BIAS), (8200, 768, 256, EPI_BIAS_RES),
     (50395, 768, 256, EPI_BIAS_RES), (66000, 1000, 128, EPI_SCALE),      # 2.31 / 4.03 rounds of 256 tiles
+    (50432, 768, 768, EPI_BIAS_RES), (50395, 3072, 768, EPI_BIAS_QGELU),       # the batch-256 launch shapes: 2.31 / 9.23 rounds
 ])
 def test_gemm_f16_large_tiles(lib, variant, M, N, K, epi):
     """Shapes with >= 64 tiles of 256 x 256, which take the 256-row tile kernels (variant 6: double-buffered K loop; variant 8:

@@ -129,36 +129,39 @@ def test_l2_forward_prompt_and_inference(golden, key, name, tag, n_ctx):
         np.testing.assert_allclose(out.numpy(), g[f"{tag}_logits_{mode}"], atol=1e-6, err_msg=mode)
 
 
-@pytest.mark.parametrize("key,name", [("small", "small"), ("vitb16", "ViT-B/16")])
-def test_l2a_fusion_weight_and_fused_output_unconditional(golden, key, name):
-    """The `l2a` fixtures (aligned weights, 12 classes x 8 shots, every cross-validation argmax of the reference clear by
-    more than `l2a_meta_margin`): the whole generation job of the oracle -- features -> classifiers -> argmax counts -> F1 ->
+@pytest.mark.parametrize("key,name,tag", [("tiny", "tiny", "l2a"), ("tiny", "tiny", "l2a1"), ("small", "small", "l2a"), ("small", "small", "l2a1"), ("vitb16", "ViT-B/16", "l2a")])
+def test_l2a_fusion_weight_and_fused_output_unconditional(golden, key, name, tag):
+    """The `l2a*` fixtures (aligned weights, every cross-validation argmax of the reference clear by more than `*_meta_margin`;
+    `l2a` = n_ctx 2, `l2a1` = n_ctx 1; every fixture family -- tiny, small, ViT-B/16 -- has one): the whole generation job of the oracle -- features -> classifiers -> argmax counts -> F1 ->
     fusion_weight -> the four EVAL_MODE outputs -- against the reference's recorded tensors, fusion_weight EXACTLY."""
     g = golden(key)
-    spec, sd_np, pl_np, labels, img, qlab, q = aligned_case(g, name)
-    C, S, tau = len(g["l2a_classnames"]), int(g["l2a_meta_shots"]), float(g["l2a_meta_tau"])
+    spec, sd_np, pl_np, labels, img, qlab, q = aligned_case(g, name, tag)
+    n_ctx = int(g[f"{tag}_meta_n_ctx"]) if f"{tag}_meta_n_ctx" in g.files else 2
+    C, S, tau = len(g[f"{tag}_classnames"]), int(g[f"{tag}_meta_shots"]), float(g[f"{tag}_meta_tau"])
     sd = O.convert_weights(O.to_torch(sd_np), "fp16")
-    tok = torch.from_numpy(g["l2a_tokenized_prompts"])
+    tok = torch.from_numpy(g[f"{tag}_tokenized_prompts"])
     ls = sd["logit_scale"].float().exp()
     # the fixture's contract, re-checked here: no near-tie in the reference's own logits
-    ref_f = torch.from_numpy(g["l2a_eval_feat4cls"]).half()
+    ref_f = torch.from_numpy(g[f"{tag}_eval_feat4cls"]).half()
     for k in ("mm_classifier", "vision_classifier", "text_classifier"):
-        lg = O.cross_validation_logits(ref_f, torch.from_numpy(g[f"l2a_saved_{k}"]).half(), ls).float().numpy()
-        assert not near_tie_classes(lg, float(g["l2a_meta_margin"])), k
+        lg = O.cross_validation_logits(ref_f, torch.from_numpy(g[f"{tag}_saved_{k}"]).half(), ls).float().numpy()
+        assert not near_tie_classes(lg, float(g[f"{tag}_meta_margin"])), k
     with torch.no_grad():
-        r = O.forward_prompt(torch.from_numpy(img), torch.from_numpy(labels), tok, sd, O.to_torch(pl_np), 2, tau,
-                             int(g["l2a_meta_classes_per_batch"]), "fp16")
+        r = O.forward_prompt(torch.from_numpy(img), torch.from_numpy(labels), tok, sd, O.to_torch(pl_np), n_ctx, tau,
+                             int(g[f"{tag}_meta_classes_per_batch"]), "fp16")
         qf = O.l2_normalize(O.encode_image(torch.from_numpy(q).half(), sd))
     for k in ("text_classifier", "vision_classifier", "mm_classifier"):
-        assert_cosine(r[k].numpy(), g[f"l2a_saved_{k}"], 2e-5, k)
-    assert_cosine(r["visual_tokens"].float().numpy(), g["l2a_saved_visual_tokens"], 2e-5, "visual_tokens")
-    assert_cosine(r["eval_feat4cls"].float().numpy(), g["l2a_eval_feat4cls"], 2e-5, "eval_feat4cls")
-    np.testing.assert_allclose(r["fusion_weight"].numpy(), g["l2a_saved_fusion_weight"], atol=1e-6)
-    assert len(np.unique(np.round(g["l2a_saved_fusion_weight"], 3), axis=0)) >= 4, "degenerate fixture"
+        assert_cosine(r[k].numpy(), g[f"{tag}_saved_{k}"], 2e-5, k)
+    assert_cosine(r["visual_tokens"].float().numpy(), g[f"{tag}_saved_visual_tokens"], 2e-5, "visual_tokens")
+    assert_cosine(r["eval_feat4cls"].float().numpy(), g[f"{tag}_eval_feat4cls"], 2e-5, "eval_feat4cls")
+    np.testing.assert_allclose(r["fusion_weight"].numpy(), g[f"{tag}_saved_fusion_weight"], atol=1e-6)
+    assert len(np.unique(np.round(g[f"{tag}_saved_fusion_weight"], 3), axis=0)) >= min(4, C // 2), "degenerate fixture"
     for mode in ("fusion", "text", "vision", "multimodal"):
         out = O.inference_logits(qf, r["mm_classifier"].half(), r["vision_classifier"].half(), r["text_classifier"].half(),
                                  r["fusion_weight"], ls, mode)
-        assert_cosine(out.numpy(), g[f"l2a_logits_{mode}"], 1e-3, mode)      # logits ~100 carry fp16 steps of 0.06
+        # logits ~100 carry fp16 steps of 0.06, which the softmax turns into 6 % steps of a probability; the 128-wide tiny model has the
+        # fewest terms to average them out (same allowance as the per-image outputs of the older tiny fixtures)
+        assert_cosine(out.numpy(), g[f"{tag}_logits_{mode}"], 5e-3 if name == "tiny" else 1e-3, mode)
 
 
 def test_state_dict_keys(golden):
