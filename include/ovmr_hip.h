@@ -155,6 +155,13 @@ int ovmr_zeroshot_logits(ovmr_handle* h, const void* feats_f16, int B, const voi
 /* exp(logit_scale) as held by the handle (set through ovmr_set_weight("logit_scale")). */
 float ovmr_logit_scale(const ovmr_handle* h);
 
+/* Device half of the test transform -- replaces ToTensor + Normalize of _build_transform_test
+ * (Dassl.pytorch/dassl/data/transforms/transforms.py:495-526; mean / std of configs/trainers/MM_CLS_OP/*.yaml:14-15) and the
+ * .type(fp16) of trainers/mm_classifier_one_prompt.py:243,306.  u8_hwc: DEVICE uint8 [B, R, R, 3], the decoded, bicubic-resized and
+ * centre-cropped images (the host's share of the transform); out_f16: fp16 [B, 3, R, R] = h(((u / 255) - mean[c]) / std[c]), the
+ * fp32 arithmetic of torchvision bit for bit.  mean3 / std3 are HOST pointers to three floats.  R % 8 == 0.  Needs no handle. */
+int ovmr_preprocess_u8(const void* u8_hwc, int B, int R, const float* mean3, const float* std3, void* out_f16, ovmr_stream stream);
+
 /* Closed-form FLOP counts.  ovmr_flops_per_image is the ALGORITHMIC count of the reference's
  * VisionTransformer.forward (every block over every token, clip/model.py:411-428: 35.127 GFLOP for ViT-B/16);
  * ovmr_flops_per_image_executed is what ovmr_encode_image launches: its last block runs attention / out_proj / MLP for the

@@ -9,11 +9,14 @@ keeps the flags of `scripts/mm_cls/generate_classifier.sh:30-44` / `train.py:183
 (`--output-dir --model-dir --load-epoch --eval_mode --eval_tau --n_ctx --seed`, trailing `KEY VALUE` opts
 `DATASET.NUM_SHOTS`, `TEST.BATCH_SIZE`); yacs/Dassl are not needed.  Data layout (datasets/imagenet.py:146-159):
 `<root>/<split>/<class folder>/<image>`; `<root>/classnames.txt` lines "<folder> <class name>" (optional: folder names
-are used otherwise).  The exemplar (eval) set is the first NUM_SHOTS images of every class folder of `--eval-split`
-(default "train"), the test set is every image of `--test-split` (default "val").
+are used otherwise).  The exemplar (eval) set is NUM_SHOTS images per class folder of `--eval-split` (default "train") drawn
+under `--seed` exactly as the reference's generate_fewshot_dataset draws them, the test set is every image of `--test-split`
+(default "val").
 
-Host-side image decoding (PIL) is NOT part of the accelerated path; it is the next bottleneck once the encoder runs
-at > 20 k images/s.
+Input pipeline (ovmr_amd/loader.py): `--workers` processes decode + resize + crop to uint8 into a page-locked shared ring, a side
+stream uploads a batch and runs ovmr_preprocess_u8 (normalise + fp16 on the GPU) while the encoder works on the previous one.
+JPEG decode on the host's cores remains the bound of the whole job (a few thousand images/s against ~29 k for the encoder): the
+runner prints end-to-end images/s and the fraction of the time the encoder sat idle.
 """
 from __future__ import annotations
 
@@ -100,16 +103,36 @@ class FolderLoader:
             yield {"img": imgs, "label": torch.tensor([l for _, l in chunk], dtype=torch.long)}
 
 
-def exemplar_items(items: Sequence[Tuple[str, int]], shots: int) -> List[Tuple[str, int]]:
-    """NUM_SHOTS images per class, S consecutive rows per class (RandomClassSampler contract)."""
+def fewshot_items(items: Sequence[Tuple[str, int]], shots: int, seed: int = 1) -> List[Tuple[str, int]]:
+    """The few-shot subset, drawn as the reference draws it: `random.seed(SEED)` (set_random_seed, train.py:183-186), then per
+    class, in order of first appearance, `random.sample(items_of_the_class, NUM_SHOTS)`; a class with fewer images keeps them
+    all and draws nothing (Dassl.pytorch/dassl/data/datasets/base_dataset.py:175-205 generate_fewshot_dataset, repeat=False).
+    Same dataset + same seed = the same images as the reference's run (tests/golden/fewshot.npz holds the reference's picks)."""
+    import random
+    rng = random.Random(seed)                  # the stream of the global generator after random.seed(seed)
     per: Dict[int, List[Tuple[str, int]]] = {}
     for it in items:
         per.setdefault(it[1], []).append(it)
     out = []
-    for label in sorted(per):
-        if len(per[label]) < shots:
-            raise ValueError(f"class {label} has {len(per[label])} images, NUM_SHOTS = {shots}")
-        out.extend(per[label][:shots])
+    for its in per.values():
+        out.extend(rng.sample(its, shots) if len(its) >= shots else its)
+    return out
+
+
+def exemplar_items(items: Sequence[Tuple[str, int]], shots: int, seed: int = 1) -> List[Tuple[str, int]]:
+    """`fewshot_items` laid out for the eval-set loader: exactly NUM_SHOTS consecutive rows per class.  A class
+    with fewer images is filled up with replacement, as RandomClassSampler does (samplers.py:148-149, there from numpy's global
+    generator at iteration time; here from RandomState(seed)).  The reference additionally shuffles the order of the shots and
+    of the classes (samplers.py:117-181), which the path does not depend on: the aggregator has no positional embedding."""
+    per: Dict[int, List[Tuple[str, int]]] = {}
+    for it in fewshot_items(items, shots, seed):
+        per.setdefault(it[1], []).append(it)
+    fill = np.random.RandomState(seed)
+    out = []
+    for its in per.values():
+        if len(its) < shots:
+            its = its + [its[int(k)] for k in fill.choice(len(its), size=shots - len(its), replace=True)]
+        out.extend(its)
     return out
 
 
@@ -132,6 +155,10 @@ def parse(argv=None):
     ap.add_argument("--eval-split", default="train")
     ap.add_argument("--test-split", default="val")
     ap.add_argument("--device", default="cuda:0")
+    ap.add_argument("--workers", type=int, default=8,
+                    help="decode worker processes of the pipelined loader (DATALOADER.NUM_WORKERS of the reference: 8); 0 = decode in this thread")
+    ap.add_argument("--prefetch", type=int, default=3, help="batches the workers decode ahead")
+    ap.add_argument("--fast-decode", action="store_true", help="JPEG draft mode (DCT-domain downscale): faster, pixels differ slightly from the reference's")
     ap.add_argument("opts", nargs=argparse.REMAINDER, help="KEY VALUE pairs: DATASET.NUM_SHOTS, TEST.BATCH_SIZE")
     return ap.parse_args(argv)
 
@@ -166,13 +193,30 @@ def main(argv=None) -> Dict[str, float]:
                                prompt_learner_state=pl_state, reserve=(batch, 256, max(1024, len(classnames))))
     import torch.distributed as dist
     rank, world = (dist.get_rank(), dist.get_world_size()) if dist.is_available() and dist.is_initialized() else (0, 1)
-    eval_loader = FolderLoader(exemplar_items(eval_all, shots), batch // shots * shots, size, rank, world, len(classnames))
+    exemplars = exemplar_items(eval_all, shots, args.seed)
     _, test_items = list_split(args.root, args.test_split)
+    if args.workers > 0:
+        from .loader import PipelinedFolderLoader
+        kw = dict(workers=args.workers, prefetch=args.prefetch, device=args.device, fast_decode=args.fast_decode)
+        eval_loader = PipelinedFolderLoader(exemplars, batch // shots * shots, size, rank, world, len(classnames), **kw)
+        test_loader = PipelinedFolderLoader(test_items, batch, size, **kw)
+    else:
+        eval_loader = FolderLoader(exemplars, batch // shots * shots, size, rank, world, len(classnames))
+        test_loader = FolderLoader(test_items, batch, size)
     evaluator = Classification(len(classnames), classnames, device=args.device)
-    for b in FolderLoader(test_items, batch, size):
+    model.forward_prompt(eval_loader)        # the reference does this inside the first forward (:341-342); up front it keeps the two loaders' statistics apart
+    for b in test_loader:
         out = model(b["img"], eval_set_loader=eval_loader, label=b["label"])
         evaluator.process(out, b["label"])
-    return dict(evaluator.evaluate(args.output_dir))
+    results = dict(evaluator.evaluate(args.output_dir))
+    for name, ld in (("exemplar set", eval_loader), ("test set", test_loader)):
+        st = getattr(ld, "stats", None)
+        if st:
+            print(f"input pipeline, {name}: {st['images']} images in {st['wall_s']:.2f} s = {st['images_per_s']:.0f} img/s end to end "
+                  f"({st['workers']} decode workers), encoder idle {100 * st['encoder_idle_fraction']:.0f} % of the time, "
+                  f"host blocked on decode {st['decode_wait_s']:.2f} s")
+            results[f"pipeline_{name.split()[0]}"] = st
+    return results
 
 
 if __name__ == "__main__":

@@ -177,5 +177,6 @@ int launch_argmax_counts(const half_t* logits, int ld, const int* labels, int R,
 int launch_argmax_reduce(const float* partial, int tiles, const int* labels, int R, int C, int* tp, int* n_pred, hipStream_t s);
 int launch_fusion_weights(const int* counts, const int* n_label, int C, float tau, float* out, hipStream_t s);
 int launch_scale_f16(const half_t* x, half_t* y, float scale, long n, hipStream_t s);
+int launch_preprocess_u8(const uint8_t* in, half_t* out, int B, int R, const float* mean3, const float* std3, hipStream_t s);
 int launch_fused_softmax(const half_t* l0, const half_t* l1, const half_t* l2, const float* w, int n_mod,
                          float* out, int B, int C, hipStream_t s);

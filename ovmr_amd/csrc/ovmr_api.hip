@@ -283,6 +283,13 @@ int ovmr_set_option(ovmr_handle* h, const char* key, int value) {
 
 float ovmr_logit_scale(const ovmr_handle* h) { return h ? h->logit_scale_exp : 0.f; }
 
+int ovmr_preprocess_u8(const void* u8_hwc, int B, int R, const float* mean3, const float* std3, void* out_f16, ovmr_stream stream) {
+    if (B == 0) return 0;
+    if (!u8_hwc || !out_f16 || !mean3 || !std3 || B < 0 || R <= 0) return OVMR_E_ARG;
+    if (R % 8) return OVMR_E_SHAPE;
+    return launch_preprocess_u8((const uint8_t*)u8_hwc, (half_t*)out_f16, B, R, mean3, std3, (hipStream_t)stream);
+}
+
 int ovmr_set_weight(ovmr_handle* h, const char* name_c, const void* data, int dtype, int ndim,
                     const int64_t* shape, ovmr_stream stream) {
     if (!h || !name_c || !data || (dtype != OVMR_F16 && dtype != OVMR_F32) || ndim < 0 || ndim > 4) return OVMR_E_ARG;

@@ -277,6 +277,46 @@ int launch_add_f16(const half_t* a, const half_t* b, half_t* out, long n, hipStr
     hipLaunchKernelGGL(add_f16_kernel, dim3(grid1d(n)), dim3(256), 0, s, a, b, out, n);
     return (int)hipGetLastError();
 }
+// ToTensor + Normalize of the test transform (Dassl.pytorch/dassl/data/transforms/transforms.py:495-526) + the fp16 cast of
+// trainers/mm_classifier_one_prompt.py:243 on the device: uint8 [B, R, R, 3] (what decode + bicubic resize + centre crop leave on
+// the host) -> fp16 [B, 3, R, R], x = ((u / 255) - mean[c]) / std[c] in fp32 with IEEE division, i.e. bit for bit the fp32 tensor
+// torchvision builds, then rounded to fp16.  One thread = 8 consecutive pixels of a row: 24 B in, 3 x 16 B out (one per plane).
+__global__ void preprocess_u8_kernel(const uint8_t* __restrict__ in, half_t* __restrict__ out, long groups, int R,
+                                     float m0, float m1, float m2, float s0, float s1, float s2) {
+    const long g = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= groups) return;
+    const int gpr = R / 8;                               // groups per row
+    const long row = g / gpr;                            // b * R + y
+    const int x0 = (int)(g - row * gpr) * 8;
+    const long b = row / R;
+    const int y = (int)(row - b * R);
+    const uint8_t* src = in + (row * R + x0) * 3;
+    uint32_t w[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) w[k] = ((const uint32_t*)src)[k];      // rows are R * 3 bytes, x0 * 3 = 24 * n: 4-byte aligned when R % 4 == 0
+    const float mean[3] = {m0, m1, m2}, sd[3] = {s0, s1, s2};
+    half8_t o[3];
+#pragma unroll
+    for (int p = 0; p < 8; ++p)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const int byte = p * 3 + c;
+            const float u = (float)((w[byte >> 2] >> ((byte & 3) * 8)) & 0xff);
+            o[c][p] = (half_t)((u / 255.0f - mean[c]) / sd[c]);
+        }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) *(half8_t*)(out + ((b * 3 + c) * R + y) * (long)R + x0) = o[c];
+}
+
+int launch_preprocess_u8(const uint8_t* in, half_t* out, int B, int R, const float* mean3, const float* std3, hipStream_t s) {
+    if (B <= 0) return 0;
+    if (R % 8) return -2;
+    const long groups = (long)B * R * (R / 8);
+    hipLaunchKernelGGL(preprocess_u8_kernel, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, s, in, out, groups, R,
+                       mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2]);
+    return (int)hipGetLastError();
+}
+
 int launch_scale_f16(const half_t* x, half_t* y, float scale, long n, hipStream_t s) {
     if (n <= 0) return 0;
     hipLaunchKernelGGL(scale_f16_kernel, dim3(grid1d(n)), dim3(256), 0, s, x, y, scale, n);

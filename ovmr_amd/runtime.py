@@ -51,6 +51,7 @@ SIGNATURES = {
     "ovmr_fused_logits": (c_i, [c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_i, c_i, c_p, c_p]),
     "ovmr_zeroshot_logits": (c_i, [c_p, c_p, c_i, c_p, c_i, c_p, c_p]),
     "ovmr_logit_scale": (ctypes.c_float, [c_p]),
+    "ovmr_preprocess_u8": (c_i, [c_p, c_i, c_i, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float), c_p, c_p]),
     "ovmr_flops_per_image": (ctypes.c_double, [c_p]),
     "ovmr_flops_per_image_executed": (ctypes.c_double, [c_p]),
     "ovmr_flops_per_prompt": (ctypes.c_double, [c_p, c_i]),

@@ -118,8 +118,8 @@ def test_runner_helpers(tmp_path):
     assert cli.read_classnames(str(tmp_path), folders) == ["tench fish", "goldfish"]
     ex = cli.exemplar_items(items, 2)
     assert [l for _, l in ex] == [0, 0, 1, 1]
-    with pytest.raises(ValueError):
-        cli.exemplar_items(items, 5)
+    over = cli.exemplar_items(items, 5)                 # more shots than images: filled up with replacement (samplers.py:148-149)
+    assert [l for _, l in over] == [0] * 5 + [1] * 5 and set(over) == set(items)
     batches = list(cli.FolderLoader(ex, 2, 32))
     assert len(batches) == 2 and batches[0]["img"].shape == (2, 3, 32, 32) and batches[0]["label"].tolist() == [0, 0]
     x = cli.test_transform(Image.fromarray(np.full((50, 80, 3), 128, dtype=np.uint8)), 32)
@@ -207,3 +207,21 @@ def test_default_tokenizer_from_environment(tmp_path, monkeypatch):
     os.replace(p, tmp_path / "clip" / "bpe_simple_vocab_16e6.txt.gz")
     assert modules.default_tokenizer().encode("a") == tk.encode("a")
     modules._DEFAULT_TOKENIZER.clear()
+
+
+def test_fewshot_draw_matches_the_reference():
+    """cli.fewshot_items against what the reference's own generate_fewshot_dataset picked after random.seed(seed)
+    (tests/golden/gen_fewshot.py -> fewshot.npz): the same items in the same order, for three seeds and two shot counts, incl.
+    classes with fewer images than shots (kept whole).  exemplar_items lays them out as S consecutive rows per class."""
+    from ovmr_amd import cli
+    g = np.load(os.path.join(REPO, "tests", "golden", "fewshot.npz"))
+    items = list(zip(g["paths"].tolist(), [int(x) for x in g["labels"]]))
+    for seed in (1, 2, 3):
+        for shots in (4, 8):
+            got = [p for p, _ in cli.fewshot_items(items, shots, seed)]
+            assert got == g[f"picked_seed{seed}_shots{shots}"].tolist(), (seed, shots)
+            ex = cli.exemplar_items(items, shots, seed)
+            labels = [l for _, l in ex]
+            assert len(ex) == 7 * shots and all(len(set(labels[i:i + shots])) == 1 for i in range(0, len(ex), shots))
+            assert set(p for p, _ in ex) == set(got)                       # the fill only repeats drawn images
+    assert [p for p, _ in cli.fewshot_items(items, 4, 1)] != [p for p, _ in cli.fewshot_items(items, 4, 2)]
