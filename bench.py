@@ -32,6 +32,19 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 
+# One-flag lines for the configurations of BASELINE.json ("metric" = configs[3]-style headline job = the default; c2 / c3 / c5 =
+# configs[1] / [2] / [4] at N = 1).  A preset only overrides defaults; explicit flags win.  For c3 the VALUE is the inference phase
+# alone (query images / s: generation is set-up there), for the others the whole job as for the metric.
+PRESETS = {
+    "metric": {"about": "ViT-B/16, 1000 classes x 16 shots + 4096 queries (the headline metric)", "set": {}},
+    "c2": {"about": "ViT-B/16, 100 classes x 8 shots generation + 1024 queries", "set": {"classes": 100, "shots": 8, "queries": 1024, "classes_per_batch": 96}},
+    "c3": {"about": "ViT-B/16 fusion inference at batch 256 against 1000 x 16-shot classifiers; value = inference images/s",
+           "set": {"queries": 16384}, "value": "inference"},
+    "c5": {"about": "ViT-L/14@336px, 1000 classes x 32 shots + 512 queries (the MFMA-bound stress configuration)",
+           "set": {"model": "ViT-L/14@336px", "shots": 32, "queries": 512, "batch": 128, "query_batch": 128, "classes_per_batch": 128}},
+}
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -50,6 +63,8 @@ def parse():
     ap.add_argument("--attn", type=int, default=int(os.environ.get("OVMR_ATTN", "3")))
     ap.add_argument("--ln-fold", type=int, default=int(os.environ.get("OVMR_LN_FOLD", "1")),
                     help="1: ln_1/ln_2 folded into the consuming GEMM epilogue; 0: separate LayerNorm kernels")
+    ap.add_argument("--preset", default="metric", choices=sorted(PRESETS),
+                    help="one BASELINE.json configuration per flag: " + "; ".join(f"{k} = {v['about']}" for k, v in PRESETS.items()))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-dist", action="store_true",
                     help="N = 1 only: initialise a one-rank nccl (= RCCL) process group and take the sharded path, so that the packed "
@@ -61,7 +76,12 @@ def parse():
     ap.add_argument("--cpu-reps", type=int, default=3)
     ap.add_argument("--cpu-procs", type=int, default=0, help="CPU worker processes (0: usable CPUs // --cpu-threads)")
     ap.add_argument("--cpu-timeout", type=float, default=240.0, help="give up on the CPU baseline after this many seconds")
-    return ap.parse_args()
+    args = ap.parse_args()
+    given = {a.split("=")[0] for a in sys.argv[1:] if a.startswith("--")}
+    for key, val in PRESETS[args.preset]["set"].items():          # a preset moves defaults only: explicit flags win
+        if "--" + key.replace("_", "-") not in given:
+            setattr(args, key, val)
+    return args
 
 
 def main():
@@ -126,15 +146,24 @@ def main():
     q_img = torch.randn((q1 - q0, 3, R, R), generator=ig, device=dev).half()
     loader = ResidentEvalSet(ex_img, torch.arange(c0, c1, device=dev), S, args.classes_per_batch, presharded=True)
 
-    def step():
+    infer_only = PRESETS[args.preset].get("value") == "inference"    # c3: the classifiers are set-up, the step is the query loop
+
+    def generate():
         if not sharded:
             model.zero_shot_classifier = model.prompt_learner.zero_shot_classifier = \
                 model.prompt_learner.encode_zero_shot(model.tokenized_prompts)     # part of the job (:118-126)
         model.forward_prompt(loader)
+
+    def step():
+        if not infer_only:
+            generate()
         outs = None
         for b in range(0, q_img.shape[0], args.query_batch):
             outs = model(q_img[b:b + args.query_batch])
         return outs
+
+    if infer_only:
+        generate()
 
     def barrier():
         if sharded:
@@ -166,9 +195,9 @@ def main():
         model(q_img[b:b + args.query_batch])
     torch.cuda.synchronize(); ti = time.perf_counter() - ti
 
-    images_per_step = C * S + Q
+    images_per_step = Q if infer_only else C * S + Q
     value = images_per_step * args.steps / dt
-    roof = measure_roofline(eng, spec, args, dev, (c1 - c0) * S, q1 - q0) if rank == 0 else None
+    roof = measure_roofline(eng, spec, args, dev, 0 if infer_only else (c1 - c0) * S, q1 - q0) if rank == 0 else None
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(spec, sd, pl, tok, args, n_ctx) if args.cpu_sample_classes > 0 else None   # 0: profiling runs skip the CPU leg
@@ -176,7 +205,8 @@ def main():
     if rank == 0:
         flops_img, flops_run = eng.flops_per_image(), eng.flops_per_image_executed()
         line = {
-            "metric": "images/sec ViT-B/16 encode+fusion, 1k-class×16-shot, 1/2/4/8 MI355X",
+            "metric": "images/sec ViT-B/16 encode+fusion, 1k-class×16-shot, 1/2/4/8 MI355X" if args.preset == "metric" else
+                      f"images/sec, BASELINE.json configuration {args.preset}: {PRESETS[args.preset]['about']}",
             "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1000 * dt / args.steps, 3), "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f16", "data": "synthetic",
@@ -184,7 +214,7 @@ def main():
                                    f"({C * S} exemplar images, batch {args.batch}) + {Q} query images (batch {args.query_batch}), n_ctx 2, tau 10",
                        "parallelism": f"class/query sharding over {world} rank(s); all-gather rows + all-reduce counters"
                                       + (f" (process group {dist.get_backend()}, sharded path forced)" if args.force_dist and world == 1 else ""),
-                       "gemm_variant": args.gemm, "attn_variant": args.attn, "ln_fold": args.ln_fold, "gelu_exact": args.gelu_exact,
+                       "preset": args.preset, "gemm_variant": args.gemm, "attn_variant": args.attn, "ln_fold": args.ln_fold, "gelu_exact": args.gelu_exact,
                        "images_per_step": images_per_step},
             "roofline": roof,
             "cpu_baseline": cpu,

@@ -562,6 +562,54 @@ def test_config_c5_vit_l14_336_encode(O):
     torch.cuda.empty_cache()
 
 
+@pytest.mark.timeout(1500)
+def test_config_c5_vit_l14_336_generation_end_to_end(O, tmp_path):
+    """BASELINE config 5 WHOLE on the real architecture (ViT-L/14@336px: 24 layers x width 1024, 577 tokens, embed_dim = text width
+    = 768, 12 text heads, 768-wide aggregator): classifier generation for 2 classes x 2 shots + fused inference on 2 queries through
+    CustomCLIP, against the oracle's forward_prompt / inference on the same inputs -- classifier rows, visual tokens, features, the
+    saved files and the three single-modality outputs (fusion weights of a 2-class job are decided by 4 noisy argmaxes: checked
+    through the kernel's own counters)."""
+    from ovmr_amd import modules
+    spec = synth.SPECS["ViT-L/14@336px"]
+    sd_np = synth.clip_state_dict(spec, SEED, jitter=True)
+    pl_np = synth.prompt_learner_state_dict(spec, 2, SEED, True)
+    cm = modules.CLIPModel({k: torch.from_numpy(v) for k, v in sd_np.items()}, spec)
+    C, S, tau = 2, 2, 10.0
+    tok = torch.from_numpy(synth.class_token_ids(C, seed=8))
+    cfg = modules.make_cfg(n_ctx=2, num_shots=S, eval_tau=tau, output_dir=str(tmp_path), size=336)
+    model = modules.CustomCLIP(cfg, tok, cm, prompt_learner_state={k: torch.from_numpy(v) for k, v in pl_np.items()}, reserve=(8, 8, 8))
+    labels = np.repeat(np.arange(C), S)
+    img = torch.from_numpy(synth.images(C * S, 336, 1234, labels, 0.8))
+    q = torch.from_numpy(synth.images(2, 336, 777, np.arange(2) % C, 0.8))
+    loader = [{"img": img, "label": torch.from_numpy(labels)}]
+    outs = {}
+    for mode in ("fusion", "text", "vision", "multimodal"):
+        cfg.EVAL_MODE = mode
+        outs[mode] = model(q, eval_set_loader=loader).cpu()
+        assert outs[mode].shape == (2, C) and outs[mode].dtype == torch.float32
+    sd = O.convert_weights(O.to_torch(sd_np), "fp16")
+    torch.set_num_threads(min(32, os.cpu_count()))
+    with torch.no_grad():
+        r = O.forward_prompt(img, torch.from_numpy(labels), tok, sd, O.to_torch(pl_np), 2, tau, C, "fp16")
+        qf = O.l2_normalize(O.encode_image(q.half(), sd))
+    assert_cosine(model.eval_feat4cls.float().cpu().flatten(0, 1).numpy(), r["eval_feat4cls"].float().flatten(0, 1).numpy(), COS_TOL, "eval_feat4cls")
+    assert_cosine(model.visual_tokens.float().cpu().flatten(0, 1).numpy(), r["visual_tokens"].float().flatten(0, 1).numpy(), COS_TOL, "visual tokens")
+    saved = torch.load(os.path.join(str(tmp_path), "mm_classifiers.pt"), map_location="cpu")
+    for k in ("mm_classifier", "vision_classifier", "text_classifier"):
+        assert_cosine(saved[k].numpy(), r[k].numpy(), COS_TOL, k)
+    ls = sd["logit_scale"].float().exp()
+    for mode in ("text", "vision", "multimodal"):
+        ref = O.inference_logits(qf, r["mm_classifier"].half(), r["vision_classifier"].half(), r["text_classifier"].half(),
+                                 r["fusion_weight"], ls, mode)
+        assert_cosine(outs[mode].numpy(), ref.numpy(), 5 * COS_TOL, mode)       # two-class softmax of logits ~100
+    counts = model.xval_counts.cpu()
+    from_counts = torch.stack([O.f1_from_counts(counts[m, 0], counts[m, 1], torch.full((C,), S)) for m in range(3)], -1)
+    np.testing.assert_allclose(saved["fusion_weight"].numpy(), (tau * from_counts).softmax(-1).numpy(), atol=1e-6)
+    assert int(counts[:, 1].sum()) == 3 * C * S
+    del model, cm
+    torch.cuda.empty_cache()
+
+
 def test_entry_points_are_graph_capturable():
     """include/ovmr_hip.h promises: no allocation, no host sync inside the compute calls.  Capture encode_image and the
     fusion head into a HIP graph on a side stream, replay on new data, compare with the eager result."""
