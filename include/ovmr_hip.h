@@ -65,7 +65,8 @@ const char* ovmr_version(void);
 /* Kernel-variant switch used by tests/bench to A/B implementations: key in {"gemm","attn","ln_fold","xval_fused","gelu_exact"}.
  * "gemm" (default 8): 8 = 256-row LDS-DMA tiles with the ping-pong K loop (half-tile staging, counted waits), 6 = the same tiles with the double-buffered
  *   K loop, 0 = the 128x128 register-staged kernel everywhere (LayerNorm-folding and fused-argmax launches still take the tile kernel).
- * "attn" (default 3): 3 = single-pass persistent kernel where the shape is its own (non-causal, 192 < L <= 208), else as 1;
+ * "attn" (default 3): 3 = single-pass persistent kernel where the shape is its own (non-causal, 192 < L <= 208), the 32x32x16 flash
+ *   kernel (= 5) for non-causal L >= 256 (ViT-L), else as 1; 5 = that kernel where it applies, else as 1;
  *   4 = the same arithmetic with free-running producer / consumer waves (LDS flags instead of the workgroup barrier), same shapes;
  *   1 = flash-style LDS-DMA kernel for L >= 128, else as 0; 0 = the plain flash-style kernel.
  * "ln_fold" (default 1): ln_1 / ln_2 of the fp16 towers are folded into the consuming GEMM where the shape allows

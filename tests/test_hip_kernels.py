@@ -11,7 +11,7 @@ pytestmark = pytest.mark.gpu
 
 EPI_NONE, EPI_BIAS, EPI_BIAS_QGELU, EPI_BIAS_RES, EPI_PATCH, EPI_SCALE = range(6)
 GEMM_VARIANTS = [0, 6, 8]       # 0: 128x128 register-staged; 6 / 8: 256-row LDS-DMA tiles (double-buffered / ping-pong K loop)
-ATTN_VARIANTS = [0, 1, 3]        # (variant 4, the barrier-free form of 3, lives in the experiment build only)
+ATTN_VARIANTS = [0, 1, 3, 5]     # 5: 32x32x16 flash kernel for L >= 256 (variant 3 routes ViT-L there); variant 4 lives in the experiment build only
 
 
 @pytest.fixture(scope="module")
@@ -175,12 +175,16 @@ def _ref_attention(qkv, B, L, H, causal):
 @pytest.mark.parametrize("variant", ATTN_VARIANTS)
 @pytest.mark.parametrize("B,L,H,causal", [(3, 197, 12, 0), (2, 5, 2, 0), (4, 77, 8, 1), (5, 9, 2, 1), (1, 577, 16, 0),
                                           (2, 64, 4, 0), (2, 65, 4, 1), (3, 6, 8, 1), (2, 193, 3, 0), (2, 208, 2, 0), (1, 200, 4, 0),
-                                          (2, 192, 2, 0), (2, 209, 2, 0)])     # 193..208: the single-pass kernel (variant 3)
+                                          (2, 192, 2, 0), (2, 209, 2, 0),      # 193..208: the single-pass kernel (variant 3)
+                                          # >= 256: variant 5 (ViT-L/14: 257, @336px: 577; ragged key blocks and query tiles)
+                                          (2, 257, 16, 0), (3, 577, 3, 0), (1, 256, 2, 0), (2, 300, 5, 0), (1, 353, 2, 0), (9, 288, 1, 0)])
 def test_attention_f16(lib, variant, B, L, H, causal):
     g = torch.Generator().manual_seed(B * L + H)
     qkv = (torch.randn(B * L, 3 * H * 64, generator=g)).half()
     # spike one key so the online-softmax rescale path is exercised (cdna guide rule 26)
     qkv[L // 2, H * 64:H * 64 + 64] *= 6.0
+    if L >= 256:                    # ... and one in a LATE key block of head 0 (the lazily rescaled kernels move their reference there)
+        qkv[L - 70, H * 64:H * 64 + 64] *= 9.0
     ref = _ref_attention(qkv.float(), B, L, H, causal)
     qd = qkv.cuda()
     out = torch.zeros(B * L, H * 64, dtype=torch.float16, device="cuda")

@@ -22,7 +22,8 @@ lib = runtime.load_library()
 print("library:", os.environ.get("OVMR_HIP_LIB", runtime.LIB_PATH), flush=True)
 p = lambda t: ctypes.c_void_p(t.data_ptr())
 s = lambda: ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-for name, B, L, H, causal in (("image", args.batch, 197, 12, 0), ("text", 1000, 10, 8, 1), ("text77", 256, 77, 8, 1), ("vit-l336", 32, 577, 16, 0)):
+for name, B, L, H, causal in (("image", args.batch, 197, 12, 0), ("text", 1000, 10, 8, 1), ("text77", 256, 77, 8, 1), ("vit-l336", 64, 577, 16, 0),
+                               ("vit-l336-b128", 128, 577, 16, 0), ("vit-l224", 256, 257, 16, 0)):
     if args.only and name != args.only:
         continue
     qkv = torch.randn((B * L, 3 * H * 64), device="cuda").half()
