@@ -557,7 +557,7 @@ __global__ __launch_bounds__(512) void gemm_f16_v5_kernel(GemmArgs a, int tiles_
 #pragma unroll
             for (int it = 0; it < 8; ++it) {
                 const int m = min(m0 + wm * (BM / 2) + h * 64 + it * 8 + er, a.M - 1);
-                res8[EPI == EPI_BIAS_RES ? it : 0] = *(const half8_t*)((const half_t*)a.res + (long)m * a.ldres + min(nn, a.N - 8));
+                res8[EPI == EPI_BIAS_RES ? it : 0] = *(const half8_t*)((const half_t*)a.res + (long)m * a.ldres + min(nn, a.N - 8));   // (a nontemporal load here: out_proj +3 %, c_proj equal, r03)
             }
         }
         float ln_rs[LNF ? 4 : 1], ln_ts[LNF ? 4 : 1];   // LNF: rstd and -rstd * mean of this lane's four rows
