@@ -188,6 +188,11 @@ __global__ __launch_bounds__(512) void gemm_f16_v5_kernel(GemmArgs a, int tiles_
     //     once per K-tile, in M2, never 0 inside the loop): the two half-tiles just issued stay in flight across the barriers;
     //   * the two wave rows run ONE barrier apart: while wm = 0 issues its MFMAs, wm = 1 reads fragments and issues DMA,
     //     then they swap -- each SIMD holds one wave of either row, so its matrix pipe and its LDS / VMEM issue alternate.
+    // Where a K-tile's ~3100 cycles go (r03s, tools/gemm_stamps.py, shader-clock stamps of one workgroup): per phase and wave, load work
+    // (fragment reads + DMA issue + counted wait) 360-600, wait at the mid barrier for the other row's MFMAs 120-400, the 32 MFMAs 590-640
+    // (512 back to back), phase-end barrier turn-around ~130: the half-period is MFMA segment + barrier turn-around ~ 770, the load work
+    // hides.  Taking the phase-end barrier 3 or 8 MFMAs early (so that the other row is released while this one still feeds the pipe)
+    // was bit-identical and 8-10 % SLOWER on every shape (r03s): two rows' MFMAs interleaved on one SIMD cost more than the turn-around.
     // Slot reuse (WAR): every phase retires its fragment reads (lgkmcnt(0)) BEFORE its first barrier, so a half-tile may be
     // restaged one phase after its last read; a staged half-tile is first read one phase after the counted wait + barrier that
     // retires it (RAW) -- the guide's rules for two wave groups staggered by a barrier.
@@ -247,6 +252,22 @@ __global__ __launch_bounds__(512) void gemm_f16_v5_kernel(GemmArgs a, int tiles_
     __builtin_amdgcn_sched_barrier(0);                                    \
     __builtin_amdgcn_s_barrier();                                         \
     __builtin_amdgcn_sched_barrier(0);
+    // OPT & 8192 (experiment builds, tools/gemm_stamps.py): shader-clock stamps of ONE workgroup at the points of a phase where no LDS
+    // read is outstanding (s_memtime returns through lgkmcnt) -- phase start, MFMA start (behind lgkmcnt(0) + barrier), MFMA end.
+    long long* stamp_p = nullptr;
+    if constexpr ((OPT & 8192) != 0) {
+        if (a.argmax_out && blockIdx.x == 300) stamp_p = (long long*)a.argmax_out + (long)wave * 4096;
+    }
+    int stamp_i = 0;
+#define OVMR_STAMP()                                                                                   \
+    if constexpr ((OPT & 8192) != 0) {                                                                 \
+        if (stamp_p) {                                                                                 \
+            const long long t_ = __builtin_amdgcn_s_memtime();                                         \
+            if (lane == 0) stamp_p[stamp_i] = t_;                                                      \
+            ++stamp_i;                                                                                 \
+        }                                                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                             \
+    }
 
     // prologue: tile 0 complete, two half-tiles of tile 1 in flight
     stage_half(0, hB0, 0); stage_half(0, hA0, 0); stage_half(0, hB1, 0); stage_half(0, hA1, 0);
@@ -285,21 +306,26 @@ __global__ __launch_bounds__(512) void gemm_f16_v5_kernel(GemmArgs a, int tiles_
 #define OVMR_P4_MID()                                                     \
     __builtin_amdgcn_sched_barrier(0);                                    \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                    \
+    OVMR_STAMP()                                                          \
     __builtin_amdgcn_s_barrier();                                         \
     __builtin_amdgcn_sched_barrier(0);
     for (int kt = 0; kt < nk; kt += 2) {
         const bool more = kt + 2 < nk;
         // M1 even: stage B1, A1 of the odd tile
+        OVMR_STAMP()
         read_b(bufE, 0, fb0);
         read_a(bufE, 0);
         read_b(bufE, 1, fb1);
         __builtin_amdgcn_sched_barrier(0);
         stage_half(1, hB1, kt + 1); stage_half(1, hA1, kt + 1);
         OVMR_P4_MID()
+        OVMR_STAMP()
         quadrant(0, 0, fb0);
         quadrant(0, 1, fb1);
+        OVMR_STAMP()
         OVMR_PH_END()
         // M2 even: stage B0, A0 of tile kt+2; the odd tile must have landed
+        OVMR_STAMP()
         read_a(bufE, 1);
         __builtin_amdgcn_sched_barrier(0);
         if (more) { stage_half(0, hB0, kt + 2); stage_half(0, hA0, kt + 2); }
@@ -307,34 +333,43 @@ __global__ __launch_bounds__(512) void gemm_f16_v5_kernel(GemmArgs a, int tiles_
         if (more) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         OVMR_P4_MID()
+        OVMR_STAMP()
         quadrant(1, 1, fb1);
         quadrant(1, 0, fb0);
+        OVMR_STAMP()
         OVMR_PH_END()
         // M1 odd: stage B1, A1 of tile kt+2
+        OVMR_STAMP()
         read_b(bufO, 0, fb0);
         read_a(bufO, 0);
         read_b(bufO, 1, fb1);
         __builtin_amdgcn_sched_barrier(0);
         if (more) { stage_half(0, hB1, kt + 2); stage_half(0, hA1, kt + 2); }
         OVMR_P4_MID()
+        OVMR_STAMP()
         quadrant(0, 0, fb0);
         quadrant(0, 1, fb1);
+        OVMR_STAMP()
         OVMR_PH_END()
         // M2 odd: stage B0, A0 of tile kt+3; tile kt+2 must have landed
+        OVMR_STAMP()
         read_a(bufO, 1);
         __builtin_amdgcn_sched_barrier(0);
         if (more) { stage_half(1, hB0, kt + 3); stage_half(1, hA0, kt + 3); }
         __builtin_amdgcn_sched_barrier(0);
         if (more) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         OVMR_P4_MID()
+        OVMR_STAMP()
         quadrant(1, 1, fb1);
         quadrant(1, 0, fb0);
+        OVMR_STAMP()
         OVMR_PH_END()
     }
 #undef OVMR_P4_MID
     if (wm == 0) __builtin_amdgcn_s_barrier();          // balances the extra barrier of the second wave row
     __builtin_amdgcn_sched_barrier(0);
 #undef OVMR_PH_END
+#undef OVMR_STAMP
     } else
     if (OPT & 4) {
     // K loop with the iteration boundary moved INSIDE the MFMA stream.  All of a K-tile's fragment reads are issued two steps
@@ -843,6 +878,7 @@ int launch_gemm_f16_v5(const GemmArgs& a, int variant, hipStream_t s) {
         case 28: return a.epi == EPI_BIAS_QGELU ? pick_v5<EPI_BIAS_QGELU, 16 | 64>(a, s) : pick_v5<EPI_BIAS, 16 | 64>(a, s);
         case 29: return pick_v5<EPI_BIAS, 16 | 128>(a, s);
         case 38: return (a.K % 128) == 0 ? dispatch_v5<16 | 32>(a, s) : dispatch_v5<32>(a, s);   // variant 8 with the pairwise QuickGELU
+        case 58: return pick_v5<EPI_BIAS, 16 | 8192>(a, s);   // variant 8 with shader-clock stamps of workgroup 300 (a.argmax_out = stamp buffer; tools/gemm_stamps.py)
 #endif
         case 6: return dispatch_v5<0>(a, s);
         case 8: return (a.K % 128) == 0 ? dispatch_v5<16>(a, s) : dispatch_v5<0>(a, s);   // ping-pong K loop: two K-tiles per iteration

@@ -729,6 +729,12 @@ int ovmr_debug_gemm(int f32, int variant, const void* A, const void* W, const vo
         a.argmax_out = (float*)C;
         a.C = nullptr;
     }
+#ifdef OVMR_EXPERIMENTS
+    if (variant == 58) {                                    // shader-clock stamps of the ping-pong K loop: pos = int64 [8 waves][4096] (tools/gemm_stamps.py)
+        a.argmax_out = (float*)pos;
+        a.pos = nullptr;
+    }
+#endif
     if (epi == EPI_BIAS_RES && pos) {                       // statistics epilogue: pos = fp32 [M][N/256][2] output
         a.stats_out = (float*)pos;
         a.pos = nullptr;
