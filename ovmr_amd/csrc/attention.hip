@@ -196,7 +196,7 @@ __global__ __launch_bounds__(128) void attn_f32_small(const float* __restrict__ 
 int launch_attention_f16_v1(const half_t* qkv, half_t* out, int B, int L, int Lq, int H, int causal, hipStream_t s);  // attention_v1.hip
 
 int launch_attention_f16_v3(const half_t* qkv, half_t* out, int B, int L, int Lq, int H, int causal, hipStream_t s);  // attention_v3.hip
-int launch_attention_f16_v5(const half_t* qkv, half_t* out, int B, int L, int Lq, int H, int causal, hipStream_t s);  // attention_v5.hip
+int launch_attention_f16_v5(const half_t* qkv, half_t* out, int B, int L, int Lq, int H, int causal, int mode, hipStream_t s);  // attention_v5.hip
 #ifdef OVMR_EXPERIMENTS
 int launch_attention_f16_v4(const half_t* qkv, half_t* out, int B, int L, int Lq, int H, int causal, int mode, hipStream_t s);  // attention_v4.hip
 #endif
@@ -221,12 +221,19 @@ int launch_attention_f16_q(const half_t* qkv, half_t* out, int B, int L, int Lq,
     if (variant == 3) {               // single-pass kernel for the ViT-B/16 image shape; long sequences (ViT-L: L = 257 / 577) as variant 5
         int rc = launch_attention_f16_v3(qkv, out, B, L, Lq, H, causal, s);
         if (rc != -100) return rc;
-        rc = launch_attention_f16_v5(qkv, out, B, L, Lq, H, causal, s);
+        rc = launch_attention_f16_v5(qkv, out, B, L, Lq, H, causal, 0, s);
         if (rc != -100) return rc;
         variant = 1;
     }
+#ifdef OVMR_EXPERIMENTS
+    if (variant >= 50 && variant < 66) {   // variant 5's scheduling experiments (50 + mode)
+        const int rc = launch_attention_f16_v5(qkv, out, B, L, Lq, H, causal, variant - 50, s);
+        if (rc != -100) return rc;
+        variant = 1;
+    }
+#endif
     if (variant == 5) {               // 32x32x16 flash kernel (non-causal, L >= 256); other shapes as variant 1
-        const int rc = launch_attention_f16_v5(qkv, out, B, L, Lq, H, causal, s);
+        const int rc = launch_attention_f16_v5(qkv, out, B, L, Lq, H, causal, 0, s);
         if (rc != -100) return rc;
         variant = 1;
     }

@@ -41,10 +41,11 @@ constexpr int STAGE5 = 2 * KB5 * 64;                    // halves per stage: 64 
 // attention_v3.hip: with the builtin hipcc puts an s_waitcnt vmcnt(0) in front of the first transposing V read of every key block
 // (seen in the ISA of this kernel too), which drains the two blocks in flight.  Ordering is by hand: counted wait + barrier at the
 // top of the block loop.  (Waits hipcc computes for its own loads ignore these DMAs and can therefore only be too strict.)
-__device__ __forceinline__ void glds16_asm5(const void* gsrc, unsigned lds_dst) {
+// (scalar base + 32-bit per-lane byte offset: the block walk is one scalar add, the per-lane offsets never change)
+__device__ __forceinline__ void glds16_asm5(const void* sbase, unsigned voff, unsigned lds_dst) {
     unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
 }
 
 __device__ __forceinline__ half4_t tr_read5(const half_t* p) {
@@ -52,12 +53,31 @@ __device__ __forceinline__ half4_t tr_read5(const half_t* p) {
     return __builtin_bit_cast(half4_t, r);
 }
 
+#ifdef OVMR_EXPERIMENTS
+// SCH & 8: shader-clock stamps of one workgroup (tools/attn_stamps.py): eight per key block and wave
+__device__ long long g_attn5_stamps[4 * 256];
+#define A5_STAMP()                                                                     \
+    if constexpr ((SCH & 8) != 0) {                                                    \
+        if (stamp_on && stamp_i < 256) {                                               \
+            const long long t_ = __builtin_amdgcn_s_memtime();                         \
+            if (lane == 0) g_attn5_stamps[wave * 256 + stamp_i] = t_;                  \
+            ++stamp_i;                                                                 \
+        }                                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                             \
+    }
+#else
+#define A5_STAMP()
+#endif
+
 // STAGES5: LDS ring depth; RS_MFMA: row sums from the matrix pipe (ones . P^T, 16 more registers) or 32 v_add_f32 per block.  Measured
 // (r03p; 64 x 16 x 577 / 128 x 16 x 577 / 256 x 16 x 257, us): <3, MFMA> 142 / 276 / 168, <3, VALU> 144 / 281 / 167, <2, VALU> 140 / 263 / 157,
 // <2, MFMA> 146 / 275 / 170.  <2, false> is what the launcher runs.
-template <int STAGES5, bool RS_MFMA>
-__global__ __launch_bounds__(256, STAGES5 == 3 ? 3 : 4) void attn_f16_v5(const half_t* __restrict__ qkv, half_t* __restrict__ out,
-                                                                        int L, int Lq, int H, int nT, int nWG, int nBH, float scale_log2e) {
+// NW: waves (32-row query tiles) per workgroup, 3 or 4: the launcher takes the one that wastes fewer wave slots (L = 257: 9 tiles = 3 x 3).
+// SCH (experiment build): 1 = the two score chains interleaved, 2 = the next block's DMA issued behind the score MFMAs.
+template <int STAGES5, bool RS_MFMA, int NW, int SCH>
+__global__ __launch_bounds__(NW * 64, STAGES5 == 3 ? 3 : 4) void attn_f16_v5(const half_t* __restrict__ qkv, half_t* __restrict__ out,
+                                                                           int L, int Lq, int H, int nT, int nWG, int nBH, float scale_log2e) {
+    static_assert(STAGES5 == 2 || NW == 4, "the counted wait of the three-stage ring assumes four DMA instructions per wave");
     __shared__ __attribute__((aligned(16))) half_t smem[STAGES5 * STAGE5];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -71,7 +91,9 @@ __global__ __launch_bounds__(256, STAGES5 == 3 ? 3 : 4) void attn_f16_v5(const h
     const int hh = bh % H, b = bh / H;
     const half_t* base = qkv + (long)b * L * ld + hh * 64;
 
-    const int qt = wg * 4 + wave;                          // this wave's 32-row query tile
+    [[maybe_unused]] const bool stamp_on = (SCH & 8) && blockIdx.x == (gridDim.x / 16) * 8;      // a mid-grid workgroup, its first query tiles
+    [[maybe_unused]] int stamp_i = 0;
+    const int qt = wg * NW + wave;                         // this wave's 32-row query tile
     const bool act = qt < nT;                              // wave-uniform
     const int q = qt * 32 + r;
     half8_t qf[4];
@@ -81,34 +103,36 @@ __global__ __launch_bounds__(256, STAGES5 == 3 ? 3 : 4) void attn_f16_v5(const h
         for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const half8_t*)(base + (long)qc * ld + ks * 16 + h * 8);
     }
 
-    // staging: 16 LDS-DMA instructions of 8 rows x 128 B per block, four per wave (waves 0, 1: K rows; 2, 3: V rows).  The per-lane
-    // source pointers are set up once and advance by 64 rows per block; only a block that reaches past the last key clamps its rows.
+    // staging: 16 LDS-DMA instructions of 8 rows x 128 B per block (8 of K rows, then 8 of V rows), dealt round-robin to the waves.  The
+    // per-lane byte offsets are set up once; the block walk is a scalar base; only a block that reaches past the last key clamps its rows.
+    constexpr int NI = (16 + NW - 1) / NW;
     const int srow = lane >> 3, sslot = lane & 7;
     const unsigned lds_base = (unsigned)(uintptr_t)(lptr_t)smem;
-    const half_t* src[4];
-    int srow_t[4];
-    unsigned sdst[4];
+    unsigned soff[NI], sdst[NI];
+    int srow_t[NI];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        const int ins = wave * 4 + t, isv = ins >> 3, r0 = (ins & 7) * 8, row = r0 + srow;
+    for (int t = 0; t < NI; ++t) {
+        const int ins = wave + NW * t, isv = (ins >> 3) & 1, r0 = (ins & 7) * 8, row = r0 + srow;
         const int swz = isv ? (((row >> 1) & 1) << 2) : ((row >> 1) & 7);
         srow_t[t] = row;
-        src[t] = base + (1 + isv) * D + (long)row * ld + ((sslot ^ swz) << 3);
+        soff[t] = 2u * (unsigned)((1 + isv) * D + row * ld + ((sslot ^ swz) << 3));
         sdst[t] = lds_base + 2u * (unsigned)(isv * (KB5 * 64) + r0 * 64);
     }
-    const long blk_stride = (long)KB5 * ld;
-    auto stage = [&](int st, int kb_) {                    // called once per block, in block order: the pointers walk the keys
+    const unsigned row_bytes = 2u * (unsigned)ld;
+    auto stage = [&](int st, int kb_) {
         const int k0 = kb_ * KB5;
-        if (k0 + KB5 <= L) {                               // wave-uniform
+        const half_t* kbase = base + (long)k0 * ld;          // wave-uniform
+        if (k0 + KB5 <= L) {
 #pragma unroll
-            for (int t = 0; t < 4; ++t) glds16_asm5(src[t], __builtin_amdgcn_readfirstlane(sdst[t] + 2u * (unsigned)(st * STAGE5)));
+            for (int t = 0; t < NI; ++t)
+                if (NW * (t + 1) <= 16 || wave + NW * t < 16) glds16_asm5(kbase, soff[t], __builtin_amdgcn_readfirstlane(sdst[t] + 2u * (unsigned)(st * STAGE5)));
         } else {                                           // the last block: rows past the last key repeat it (finite values, masked below)
 #pragma unroll
-            for (int t = 0; t < 4; ++t)
-                glds16_asm5(src[t] - (long)max(k0 + srow_t[t] - (L - 1), 0) * ld, __builtin_amdgcn_readfirstlane(sdst[t] + 2u * (unsigned)(st * STAGE5)));
+            for (int t = 0; t < NI; ++t)
+                if (NW * (t + 1) <= 16 || wave + NW * t < 16)
+                    glds16_asm5(kbase, soff[t] - (unsigned)max(k0 + srow_t[t] - (L - 1), 0) * row_bytes,
+                                __builtin_amdgcn_readfirstlane(sdst[t] + 2u * (unsigned)(st * STAGE5)));
         }
-#pragma unroll
-        for (int t = 0; t < 4; ++t) src[t] += blk_stride;
     };
 
     float m_run = -INFINITY;                               // reference maximum of the exponentials (scaled domain), variant 1's lazy form
@@ -155,26 +179,47 @@ __global__ __launch_bounds__(256, STAGES5 == 3 ? 3 : 4) void attn_f16_v5(const h
     auto block = [&](auto stage_c, int kb) {
         constexpr int ST = decltype(stage_c)::value;
         // block kb has landed for THIS wave's four DMA instructions (block kb + 1 may stay in flight) ...
+        A5_STAMP()                                         // 0: block top
         if (STAGES5 == 3 && kb + 1 < nb) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                      // ... and for every wave; every wave is done with block kb - 1
         __builtin_amdgcn_sched_barrier(0);
-        if (kb + STAGES5 - 1 < nb) stage((ST + STAGES5 - 1) % STAGES5, kb + STAGES5 - 1);      // into the stage block kb - 1 occupied
+        A5_STAMP()                                         // 1: through the barrier
+        const bool more = kb + STAGES5 - 1 < nb;           // the next DMA goes into the stage block kb - 1 occupied
+        if (more && (!(SCH & 2) || !act)) stage((ST + STAGES5 - 1) % STAGES5, kb + STAGES5 - 1);
         if (!act) return;
+        A5_STAMP()                                         // 2: DMA issued
         constexpr int st_off = ST * STAGE5;
         const int nvalid = min(L - kb * KB5, KB5);
         float16_t zero16;
 #pragma unroll
         for (int k = 0; k < 16; ++k) zero16[k] = 0.f;      // (folds into the MFMA's inline constant 0: no accumulator zeroing)
         float16_t s[2];
-#pragma unroll
-        for (int sb = 0; sb < 2; ++sb) {
+        if (SCH & 1) {
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-                const half8_t kf = *(const half8_t*)(smem + koff[ks] + (st_off + sb * 32 * 64));
-                s[sb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], ks == 0 ? zero16 : s[sb], 0, 0, 0);
+#pragma unroll
+                for (int sb = 0; sb < 2; ++sb) {
+                    const half8_t kf = *(const half8_t*)(smem + koff[ks] + (st_off + sb * 32 * 64));
+                    s[sb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], ks == 0 ? zero16 : s[sb], 0, 0, 0);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int sb = 0; sb < 2; ++sb) {
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const half8_t kf = *(const half8_t*)(smem + koff[ks] + (st_off + sb * 32 * 64));
+                    s[sb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], ks == 0 ? zero16 : s[sb], 0, 0, 0);
+                }
             }
         }
+        if (SCH & 2) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (more) stage((ST + STAGES5 - 1) % STAGES5, kb + STAGES5 - 1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        A5_STAMP()                                         // 3: score MFMAs issued
         // register k of a score tile holds key (k & 3) + 8 (k >> 2) + 4 h of its 32-key half
         if (nvalid < KB5) {                                // (wave-uniform) the last block: keys >= L get -inf, i.e. p = 0
 #pragma unroll
@@ -195,6 +240,7 @@ __global__ __launch_bounds__(256, STAGES5 == 3 ? 3 : 4) void attn_f16_v5(const h
             mx = fmaxf(__builtin_bit_cast(float, (unsigned)sw[0]), __builtin_bit_cast(float, (unsigned)sw[1]));
         }
         const float mxs = mx * scale_log2e;
+        A5_STAMP()                                         // 4: row maxima (the scores are back)
         if (__builtin_amdgcn_ballot_w64(mxs > m_run + 8.0f) != 0) {      // wave-uniform: some row needs a new reference
             const float m_new = fmaxf(m_run, mxs);
             const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);   // <= 0 (first block: -inf -> 0)
@@ -207,6 +253,7 @@ __global__ __launch_bounds__(256, STAGES5 == 3 ? 3 : 4) void attn_f16_v5(const h
             } else lsum *= alpha;
         }
         const float m_ref = m_run;
+        A5_STAMP()                                         // 5: reference settled
 #pragma unroll
         for (int st = 0; st < 4; ++st) {                   // 16-key PV steps: registers 8 t .. 8 t + 7 of half sb = st >> 1, t = st & 1
             half8_t pf;
@@ -227,7 +274,9 @@ __global__ __launch_bounds__(256, STAGES5 == 3 ? 3 : 4) void attn_f16_v5(const h
                 o[blk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, o[blk], 0, 0, 0);
             }
             if (RS_MFMA) ol = __builtin_amdgcn_mfma_f32_32x32x16_f16(ones, pf, ol, 0, 0, 0);
+            if (st == 1) { A5_STAMP() }                    // 6: half of the PV steps issued
         }
+        A5_STAMP()                                         // 7: block end
     };
     // A last block of at most 16 keys -- every CLIP ViT has one: L = G*G + 1 leaves ONE key behind the last full block -- is peeled
     // into its own body: one 32-key score tile of which registers 0..7 (keys 0..15) are live, 8 exponentials, one PV step -- 7 MFMAs
@@ -337,13 +386,37 @@ __global__ __launch_bounds__(256, STAGES5 == 3 ? 3 : 4) void attn_f16_v5(const h
 
 }  // namespace
 
-// -100: shape not taken (causal, short sequences, a handful of query rows): the caller falls back to variant 1
-int launch_attention_f16_v5(const half_t* qkv, half_t* out, int B, int L, int Lq, int H, int causal, hipStream_t s) {
-    if (causal || L < 256 || Lq < 32) return -100;
-    const int nT = (Lq + 31) / 32, nWG = (nT + 3) / 4;
+namespace {
+template <int NW, int SCH>
+int launch_v5(const half_t* qkv, half_t* out, int B, int L, int Lq, int H, hipStream_t s) {
+    const int nT = (Lq + 31) / 32, nWG = (nT + NW - 1) / NW, nBH = B * H;
     const float sl2e = 0.125f * 1.4426950408889634f;
-    const int nBH = B * H;
     const dim3 grid((unsigned)((long)((nBH + 7) / 8) * 8 * nWG));
-    hipLaunchKernelGGL((attn_f16_v5<2, false>), grid, dim3(256), 0, s, qkv, out, L, Lq, H, nT, nWG, nBH, sl2e);
+    hipLaunchKernelGGL((attn_f16_v5<2, false, NW, SCH>), grid, dim3(NW * 64), 0, s, qkv, out, L, Lq, H, nT, nWG, nBH, sl2e);
     return (int)hipGetLastError();
 }
+}  // namespace
+
+// -100: shape not taken (causal, short sequences, a handful of query rows): the caller falls back to variant 1.
+// mode (experiment build): bits 0-1 = SCH, bit 2 = force four waves per workgroup, bit 3 = stamps (ovmr_debug_attn5_stamps).
+int launch_attention_f16_v5(const half_t* qkv, half_t* out, int B, int L, int Lq, int H, int causal, int mode, hipStream_t s) {
+    if (causal || L < 256 || Lq < 32) return -100;
+    const int nT = (Lq + 31) / 32;
+    const bool three = ((nT + 2) / 3) * 3 < ((nT + 3) / 4) * 4 && !(mode & 4);      // fewer idle wave slots with 3-wave workgroups
+#ifdef OVMR_EXPERIMENTS
+    switch (mode & 3) {
+        case 1: return three ? launch_v5<3, 1>(qkv, out, B, L, Lq, H, s) : launch_v5<4, 1>(qkv, out, B, L, Lq, H, s);
+        case 2: return three ? launch_v5<3, 2>(qkv, out, B, L, Lq, H, s) : launch_v5<4, 2>(qkv, out, B, L, Lq, H, s);
+        case 3: return three ? launch_v5<3, 3>(qkv, out, B, L, Lq, H, s) : launch_v5<4, 3>(qkv, out, B, L, Lq, H, s);
+        default: break;
+    }
+    if (mode & 8) return launch_v5<4, 8>(qkv, out, B, L, Lq, H, s);
+#endif
+    return three ? launch_v5<3, 0>(qkv, out, B, L, Lq, H, s) : launch_v5<4, 0>(qkv, out, B, L, Lq, H, s);
+}
+
+#ifdef OVMR_EXPERIMENTS
+extern "C" int ovmr_debug_attn5_stamps(long long* host_out, int n) {
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_attn5_stamps), (size_t)std::min(n, 4 * 256) * sizeof(long long));
+}
+#endif
