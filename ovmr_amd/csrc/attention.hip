@@ -198,6 +198,7 @@ int launch_attention_f16_v1(const half_t* qkv, half_t* out, int B, int L, int Lq
 int launch_attention_f16_v3(const half_t* qkv, half_t* out, int B, int L, int Lq, int H, int causal, hipStream_t s);  // attention_v3.hip
 int launch_attention_f16_v5(const half_t* qkv, half_t* out, int B, int L, int Lq, int H, int causal, int mode, hipStream_t s);  // attention_v5.hip
 #ifdef OVMR_EXPERIMENTS
+int launch_attention_f16_v6(const half_t* qkv, half_t* out, int B, int L, int Lq, int H, int causal, int mode, hipStream_t s);  // attention_v6.hip
 int launch_attention_f16_v4(const half_t* qkv, half_t* out, int B, int L, int Lq, int H, int causal, int mode, hipStream_t s);  // attention_v4.hip
 #endif
 
@@ -226,7 +227,12 @@ int launch_attention_f16_q(const half_t* qkv, half_t* out, int B, int L, int Lq,
         variant = 1;
     }
 #ifdef OVMR_EXPERIMENTS
-    if (variant >= 50 && variant < 66) {   // variant 5's scheduling experiments (50 + mode)
+    if (variant == 6 || (variant >= 60 && variant < 68)) {   // two query tiles per wave (60 + mode: attention_v6.hip; slower than variant 5)
+        const int rc = launch_attention_f16_v6(qkv, out, B, L, Lq, H, causal, variant == 6 ? 0 : variant - 60, s);
+        if (rc != -100) return rc;
+        variant = 1;
+    }
+    if (variant >= 50 && variant < 60) {   // variant 5's scheduling experiments (50 + mode)
         const int rc = launch_attention_f16_v5(qkv, out, B, L, Lq, H, causal, variant - 50, s);
         if (rc != -100) return rc;
         variant = 1;

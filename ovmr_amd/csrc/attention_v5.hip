@@ -18,10 +18,11 @@
 //     chunk c in slot c ^ (((r >> 1) & 1) << 2) (the 4 keys x 4 chunks of a transposing read: conflict-free); applied on the
 //     per-lane SOURCE address of the DMA and on the read (SQ_LDS_BANK_CONFLICT = 0);
 //   * the output tile leaves through LDS (the epilogue staging of gemm_f16_v5.hip): 8 rows x 128 B per store instruction.
-// Measured (profiles/r03p_attn_bench.log, 64 x 16 x 577 / 128 x 16 x 577 / 256 x 16 x 257): 140 / 263 / 157 us = 624 / 663 / 441 TFLOP/s
-// against 149 / 290 / 186 us for variant 1.  Neither pipe is the bound (profiles/r03l_pmc_attn_l577.json, an earlier form: matrix pipe
-// 30 % busy, vector ALU 67 %, 28 % of the wave cycles in s_waitcnt / barriers, 37 % in issue stalls): with 124 VGPRs and one tile per
-// wave the kernel lives on occupancy -- a fourth wave per SIMD (32 KiB ring) beat a second block in flight (48 KiB ring, 3 waves).
+// Measured (profiles/r03t_attn_bench_sched.log, 64 x 16 x 577 / 128 x 16 x 577 / 256 x 16 x 257): 131 / 250 / 151 us = 666 / 698 / 458 TFLOP/s
+// against 152 / 290 / 186 us for variant 1.  Neither pipe is the bound (profiles/r03p_pmc_attn_l577.json: matrix pipe 36 % busy, vector ALU
+// 64 %, 28 % of the wave cycles in s_waitcnt / barriers); tools/attn_stamps.py shows where a block goes, and attention_v6.hip (two tiles per
+// wave at two waves per SIMD, experiment build) that fewer, fatter waves lose: with 124 VGPRs and one tile per wave the kernel lives on
+// occupancy -- a fourth wave per SIMD (32 KiB ring) beat a second block in flight (48 KiB ring, 3 waves).
 #include "common.h"
 
 #include <algorithm>
