@@ -135,6 +135,15 @@ __global__ __launch_bounds__(512) void gemm_f16_v5_kernel(GemmArgs a, int tiles_
     };
 
     float4_t acc[MT][4];
+    // (OPT & 16384, below: the timing-only 32x32x16 form of the ping-pong K loop)
+    typedef float float16v __attribute__((ext_vector_type(16)));
+    [[maybe_unused]] float16v acc32[8];
+    if constexpr ((OPT & 16384) != 0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int k = 0; k < 16; ++k) acc32[i][k] = 0.f;
+    }
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -237,8 +246,24 @@ __global__ __launch_bounds__(512) void gemm_f16_v5_kernel(GemmArgs a, int tiles_
             fb[jj][1] = *(const half8_t*)(buf + 2 * g * SLOT + b_lane + jj * 2048 + ch1);
         }
     };
+    // OPT & 16384 (experiment builds, timing only, with NOEPI): the K loop's matrix work as v_mfma_f32_32x32x16_f16 -- the same fragment
+    // reads, half as many MFMA instructions (8 of 32 cycles on the issue port instead of 8 of 16); the products are meaningless.
     auto quadrant = [&](int hf, int g, half8_t (&fb)[2][2]) {
         __builtin_amdgcn_s_setprio(1);
+        if constexpr ((OPT & 16384) != 0) {
+#pragma unroll
+            for (int st = 0; st < 2; ++st)
+#pragma unroll
+                for (int ip = 0; ip < 2; ++ip)
+#pragma unroll
+                    for (int jj = 0; jj < 2; ++jj) {
+                        asm volatile("" :: "v"(fa[2 * ip + 1][st]));      // the fragment a real 32x32 layout would fold into its A operand
+                        acc32[(hf * 2 + g) * 2 + jj] =
+                            __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[jj][st], fa[2 * ip][st], acc32[(hf * 2 + g) * 2 + jj], 0, 0, 0);
+                    }
+            __builtin_amdgcn_s_setprio(0);
+            return;
+        }
 #pragma unroll
         for (int st = 0; st < 2; ++st)
 #pragma unroll
@@ -493,6 +518,12 @@ __global__ __launch_bounds__(512) void gemm_f16_v5_kernel(GemmArgs a, int tiles_
         for (int i = 0; i < MT; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) sum += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+        if constexpr ((OPT & 16384) != 0) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int k = 0; k < 16; ++k) sum += acc32[i][k];
+        }
         if (sum == 12345.678f) C[tid] = (half_t)sum;
         return;
     }
@@ -878,6 +909,7 @@ int launch_gemm_f16_v5(const GemmArgs& a, int variant, hipStream_t s) {
         case 28: return a.epi == EPI_BIAS_QGELU ? pick_v5<EPI_BIAS_QGELU, 16 | 64>(a, s) : pick_v5<EPI_BIAS, 16 | 64>(a, s);
         case 29: return pick_v5<EPI_BIAS, 16 | 128>(a, s);
         case 38: return (a.K % 128) == 0 ? dispatch_v5<16 | 32>(a, s) : dispatch_v5<32>(a, s);   // variant 8 with the pairwise QuickGELU
+        case 59: return pick_v5<EPI_BIAS, 16 | 128 | 16384>(a, s);   // variant 29 (K loop alone) with 32x32x16 MFMAs: timing only
         case 58: return pick_v5<EPI_BIAS, 16 | 8192>(a, s);   // variant 8 with shader-clock stamps of workgroup 300 (a.argmax_out = stamp buffer; tools/gemm_stamps.py)
 #endif
         case 6: return dispatch_v5<0>(a, s);

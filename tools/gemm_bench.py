@@ -62,7 +62,7 @@ def main():
             call = lambda v: lib.ovmr_debug_gemm(0, v, p(A), p(W), p(b), p(C), p(st), p(C), m, n, k, n, 3, 100.0, 0, 0, s())
         else:
             call = lambda v: lib.ovmr_debug_gemm(0, v, p(A), p(W), p(b), p(C) if epi == 3 else None, None, p(C), m, n, k, n, epi, 100.0, 0, 0, s())
-        if epi in (6, 7, 13) and any(12 <= v <= 19 or v in (28, 29) for v in args.variants):
+        if epi in (6, 7, 13) and any(12 <= v <= 19 or v in (28, 29, 59) for v in args.variants):
             continue                                  # timing-only ablation variants carry no LN-folding epilogues
         for v in args.variants:
             for _ in range(3):
