@@ -7,7 +7,10 @@ One STEP = one whole classifier-generation job plus fusion-mode inference, nothi
               generator -> multimodal / vision prompts -> text encoder (mm, vision, zero-shot text
               classifiers) -> cross-validation argmax counts -> F1 -> fusion weights;
   inference   --queries images in batches of --query-batch (256 = BASELINE config 3) -> image encoder -> three
-              classifier GEMMs -> softmax -> fused probabilities.
+              classifier GEMMs -> softmax -> fused probabilities; the test loop's forwards run through
+              CustomCLIP.forward_batches: every batch is its own forward of 256 images (bit-identical logits, in order),
+              two of them in flight on two handles / two streams so that one batch's partial last round of tiles is
+              filled by the other's work (--overlap 0: one at a time; `phases.inference_batches_in_flight`).
 value = (exemplar + query images of ALL ranks) / wall time of a step, inputs resident in HBM.
 With N > 1 (launched by torch.distributed.run, one process per GPU, backend nccl = RCCL) the classes
 and the queries are sharded over ranks (strong scaling of the named 1k-class job); the only data-path
@@ -58,6 +61,8 @@ def parse():
                     help="exemplar images per encoder launch sequence (768 x 197 rows = 591 row tiles: 6.9 / 20.8 / 27.7 rounds of 256 CUs "
                          "for the N = 768 / 2304 / 3072 GEMMs; 512 gives 4.6 rounds on N = 768, i.e. 8 % idle in the fifth)")
     ap.add_argument("--query-batch", type=int, default=256, help="query images per inference call (256 = BASELINE config 3)")
+    ap.add_argument("--overlap", type=int, default=-1, help="two query batches in flight on two streams (CustomCLIP.forward_batches): "
+                    "1 / 0 force it on / off, -1 = the module's rule (batches of at most 384 images)")
     ap.add_argument("--classes-per-batch", type=int, default=240, help="classes per loader batch (x shots = a multiple of --batch)")
     ap.add_argument("--gemm", type=int, default=int(os.environ.get("OVMR_GEMM", "8")))
     ap.add_argument("--attn", type=int, default=int(os.environ.get("OVMR_ATTN", "3")))
@@ -154,12 +159,16 @@ def main():
                 model.prompt_learner.encode_zero_shot(model.tokenized_prompts)     # part of the job (:118-126)
         model.forward_prompt(loader)
 
+    def query_batches():                                 # the test loader: resident images, --query-batch at a time
+        for b in range(0, q_img.shape[0], args.query_batch):
+            yield q_img[b:b + args.query_batch]
+
     def step():
         if not infer_only:
             generate()
         outs = None
-        for b in range(0, q_img.shape[0], args.query_batch):
-            outs = model(q_img[b:b + args.query_batch])
+        for outs in model.forward_batches(query_batches(), stable_inputs=True, overlap=None if args.overlap < 0 else bool(args.overlap)):
+            pass                                         # (the reference's loop hands each batch's logits to the evaluator)
         return outs
 
     if infer_only:
@@ -191,8 +200,8 @@ def main():
     barrier()
     tg = time.perf_counter(); model.forward_prompt(loader); torch.cuda.synchronize(); tg = time.perf_counter() - tg
     ti = time.perf_counter()
-    for b in range(0, q_img.shape[0], args.query_batch):
-        model(q_img[b:b + args.query_batch])
+    for _ in model.forward_batches(query_batches(), stable_inputs=True, overlap=None if args.overlap < 0 else bool(args.overlap)):
+        pass
     torch.cuda.synchronize(); ti = time.perf_counter() - ti
 
     images_per_step = Q if infer_only else C * S + Q
@@ -221,6 +230,7 @@ def main():
             "phases": {"generation_images_per_s_rank0": round((c1 - c0) * S / tg, 1),
                        "inference_images_per_s_rank0": round((q1 - q0) / ti, 1) if q1 > q0 else None,
                        "inference_query_batch": args.query_batch,
+                       "inference_batches_in_flight": 2 if (args.overlap == 1 or (args.overlap < 0 and args.query_batch <= model.OVERLAP_MAX_BATCH)) else 1,
                        "encoder_tflops_e2e_algorithmic": round(value * flops_img / 1e12, 1),
                        "encoder_tflops_e2e_executed": round(value * flops_run / 1e12, 1),
                        "e2e_frac_of_fp16_mfma_peak": round(value * flops_run / 1e12 / (2500.0 * world), 4)},

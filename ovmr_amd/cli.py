@@ -21,6 +21,7 @@ runner prints end-to-end images/s and the fraction of the time the encoder sat i
 from __future__ import annotations
 
 import argparse
+import collections
 import os
 import os.path as osp
 import sys
@@ -205,9 +206,15 @@ def main(argv=None) -> Dict[str, float]:
         test_loader = FolderLoader(test_items, batch, size)
     evaluator = Classification(len(classnames), classnames, device=args.device)
     model.forward_prompt(eval_loader)        # the reference does this inside the first forward (:341-342); up front it keeps the two loaders' statistics apart
-    for b in test_loader:
-        out = model(b["img"], eval_set_loader=eval_loader, label=b["label"])
-        evaluator.process(out, b["label"])
+    labels = collections.deque()
+
+    def test_images():
+        for b in test_loader:
+            labels.append(b["label"])
+            yield b["img"]
+
+    for out in model.forward_batches(test_images(), eval_set_loader=eval_loader):      # two test batches in flight (modules.py)
+        evaluator.process(out, labels.popleft())
     results = dict(evaluator.evaluate(args.output_dir))
     for name, ld in (("exemplar set", eval_loader), ("test set", test_loader)):
         st = getattr(ld, "stats", None)

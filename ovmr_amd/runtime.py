@@ -115,6 +115,8 @@ class Engine:
             raise OvmrError(f"ovmr_create failed with {rc}")
         self.h = h
         self.finalized = False
+        self._options: Dict[str, int] = {}       # what set_option was called with (a twin handle mirrors them: modules.CustomCLIP.forward_batches)
+        self._weights_version = 0                # bumped by every set_weight
 
     def __del__(self):
         try:
@@ -141,6 +143,7 @@ class Engine:
 
     def set_option(self, key: str, value: int):
         self._ck(self.lib.ovmr_set_option(self.h, key.encode(), int(value)), "ovmr_set_option")
+        self._options[key] = int(value)
 
     # ------------------------------------------------------------------ weights
     def set_weight(self, name: str, tensor):
@@ -153,6 +156,7 @@ class Engine:
         self._ck(rc, f"ovmr_set_weight({name})")
         torch.cuda.current_stream().synchronize()   # the source tensor may be freed by the caller right after
         self.finalized = False
+        self._weights_version += 1
 
     def load_state_dict(self, clip_sd: Dict[str, "torch.Tensor"], prompt_learner_sd: Optional[Dict] = None):
         """clip_sd: reference CLIP state dict (clip/model.py:899-936 key names); prompt_learner_sd:

@@ -17,6 +17,7 @@ hands the trainer: `dataset.classnames`, `test_loader`, `val_loader` (may be Non
 """
 from __future__ import annotations
 
+import collections
 import os
 import os.path as osp
 import random
@@ -115,10 +116,16 @@ class MM_CLS_OP:
             split = "test"
             data_loader = self.test_loader
         print(f"Evaluate on the *{split}* set")
-        for batch in data_loader:
-            input, label = self.parse_batch_test(batch)
-            output = self.model_inference(input, label=label)
-            self.evaluator.process(output, label)
+        labels = collections.deque()                 # model_inference's forwards (:504-508), two batches in flight (CustomCLIP.forward_batches)
+
+        def inputs():
+            for batch in data_loader:
+                input, label = self.parse_batch_test(batch)
+                labels.append(label)
+                yield input
+
+        for output in self.model.forward_batches(inputs(), eval_set_loader=self.eval_set_loader):
+            self.evaluator.process(output, labels.popleft())
         results = self.evaluator.evaluate(self.output_dir or None)
         return list(results.values())[0]
 

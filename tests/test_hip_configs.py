@@ -241,3 +241,57 @@ def test_config_c5_head_at_width_768(O, tmp_path):
     ref = O.inference_logits(qf, r["mm_classifier"].half(), r["vision_classifier"].half(), r["text_classifier"].half(),
                              r["fusion_weight"], ls, "fusion")
     assert_cosine(outs["fusion"].numpy()[:, ok], ref.numpy()[:, ok], COS_TOL, "fusion (classes free of near-ties)")
+
+
+def test_forward_batches_equals_forward_with_two_batches_in_flight(tmp_path):
+    """CustomCLIP.forward_batches (the test loop's forwards on two handles / two streams): every batch's logits bit-equal to
+    forward() on that batch, in order -- with resident inputs, with a loader that RECYCLES two device buffers (the pipelined
+    folder loader's behaviour: the buffer of batch i is overwritten as soon as batch i + 1 has been asked for), with a ragged
+    last batch, with a batch above the overlap limit (falls back to the single handle), and after an option change and a
+    prompt-learner reload on the first handle (the twin follows)."""
+    from ovmr_amd import modules
+    spec, sd, pl, cm = _small_clip("tiny", gain=2.0)
+    C, S, B = 12, 4, 24
+    tok = torch.from_numpy(synth.class_token_ids(C, seed=5))
+    cfg = modules.make_cfg(n_ctx=2, num_shots=S, output_dir=str(tmp_path))
+    model = modules.CustomCLIP(cfg, tok, cm, prompt_learner_state={k: torch.from_numpy(x) for k, x in pl.items()}, reserve=(64, 64, 64))
+    model.OVERLAP_MAX_BATCH = 32
+    g = torch.Generator().manual_seed(3)
+    R = spec.image_resolution
+    labels = torch.arange(C).repeat_interleave(S)
+    ex = torch.randn((C * S, 3, R, R), generator=g)
+    model.forward_prompt([{"img": ex, "label": labels}])
+    q = torch.randn((5 * B + 7, 3, R, R), generator=g).half().cuda()
+    chunks = [q[s:s + B] for s in range(0, q.shape[0], B)]
+    want = [model(c).clone() for c in chunks]
+    torch.cuda.synchronize()
+
+    got = [o.clone() for o in model.forward_batches(iter(chunks), stable_inputs=True)]
+    assert len(got) == len(want) and all(torch.equal(a, b) for a, b in zip(got, want))
+    assert getattr(model, "_twin_engine", None) is not None                    # the second handle was used
+
+    def recycling_loader():
+        bufs = [torch.empty((B, 3, R, R), dtype=torch.float16, device="cuda") for _ in range(2)]
+        for i, c in enumerate(chunks):
+            bufs[i & 1][:c.shape[0]].copy_(c)
+            yield bufs[i & 1][:c.shape[0]]
+            bufs[i & 1].fill_(float("nan"))                                    # the caller came back: the buffer is fair game
+
+    got = [o.clone() for o in model.forward_batches(recycling_loader())]
+    assert all(torch.equal(a, b) for a, b in zip(got, want))
+
+    big = q[:40]                                                               # above the limit: single handle, in order with the rest
+    seq = [chunks[0], big, chunks[1]]
+    got = [o.clone() for o in model.forward_batches(iter(seq))]
+    assert torch.equal(got[0], want[0]) and torch.equal(got[1], model(big)) and torch.equal(got[2], want[1])
+
+    model.engine.set_option("gelu_exact", 1)                                   # the twin mirrors the options of the first handle ...
+    want_exact = [model(c).clone() for c in chunks[:3]]
+    got = [o.clone() for o in model.forward_batches(iter(chunks[:3]))]
+    assert all(torch.equal(a, b) for a, b in zip(got, want_exact))
+    model.engine.set_option("gelu_exact", 0)
+    twin_before = model._twin_engine
+    model.prompt_learner.load_state_dict({k: torch.from_numpy(x) for k, x in pl.items()})   # ... and is rebuilt after a weight reload
+    got = [o.clone() for o in model.forward_batches(iter(chunks[:3]))]
+    assert model._twin_engine is not twin_before
+    assert all(torch.equal(a, b) for a, b in zip(got, want[:3]))
