@@ -466,7 +466,25 @@ class CustomCLIP:
                                    self.zero_shot_classifier, self.fusion_weight, mode)
 
     # ------------------------------------------------------------------ the test loop's forwards, two batches in flight
-    OVERLAP_MAX_BATCH = 384      # larger batches fill whole rounds of tiles by themselves; two of them in flight only contend
+    OVERLAP_MAX_TILES = 1024      # two batches in flight while the narrowest GEMM grid of ONE batch (ceil(rows / 256) x width / 256
+                                  # workgroups of 256 x 256) stays within 4 rounds of the 256 CUs; beyond that a batch's partial last round is
+                                  # a small share and two batches only contend (profiles/r03u_two_stream_sweep.log: ViT-B/16 128 / 256 / 384
+                                  # images +26 / +7 / +4 %, 512 -2 %; ViT-L/14@336px 64 images +8 %, 128 -1 %, 256 -2 %)
+
+    @property
+    def OVERLAP_MAX_BATCH(self) -> int:
+        """Images per batch up to which forward_batches keeps two batches in flight (settable; default from OVERLAP_MAX_TILES:
+        ViT-B/16 443 images, ViT-L/14@336px 113)."""
+        if getattr(self, "_overlap_max_batch", None) is not None:
+            return self._overlap_max_batch
+        sp = self.engine.spec
+        tokens = (sp.image_resolution // sp.vision_patch_size) ** 2 + 1
+        row_tiles = self.OVERLAP_MAX_TILES // max(1, sp.vision_width // 256)
+        return max(1, row_tiles * 256 // tokens)
+
+    @OVERLAP_MAX_BATCH.setter
+    def OVERLAP_MAX_BATCH(self, n: int):
+        self._overlap_max_batch = int(n)
 
     def _twin(self) -> Engine:
         """A second handle: the same weights and options, its own workspace (sized for OVERLAP_MAX_BATCH images), used from
@@ -495,8 +513,8 @@ class CustomCLIP:
         tiles = 2.31 rounds of the 256 CUs on the N = 768 GEMMs) is filled by the other batch's work.  The output of batch i
         is handed over after batch i + 1 has been enqueued; using it on the current stream is ordered after its computation.
 
-        overlap: None = for batches of at most OVERLAP_MAX_BATCH images (measured: 256 images 27.7 k -> 29.7 k img/s,
-        768 images 30.7 k -> 28.7 k; profiles/r03t_two_stream.log).  stable_inputs: the caller guarantees that a batch's
+        overlap: None = for batches of at most OVERLAP_MAX_BATCH images (measured, ViT-B/16: 256 images 27.7 k -> 29.7 k img/s,
+        768 images 30.7 k -> 28.7 k; profiles/r03t_two_stream.log, r03u_two_stream_sweep.log).  stable_inputs: the caller guarantees that a batch's
         tensor is not overwritten before its output has been handed over (a resident data set); otherwise each batch is first
         copied on the current stream, so that loaders which recycle their device buffers (loader.PipelinedFolderLoader)
         stay correct."""
@@ -514,10 +532,11 @@ class CustomCLIP:
             out.record_stream(cur)
             return out
 
+        cap = min(self.OVERLAP_MAX_BATCH, getattr(self.engine, "_reserve", (256,))[0])    # what the twin's workspace holds
         for image in batches:
             image = self.engine._dev(image)
-            use = overlap if overlap is not None else image.shape[0] <= self.OVERLAP_MAX_BATCH
-            if not use or image.shape[0] > self.OVERLAP_MAX_BATCH:
+            use = overlap if overlap is not None else image.shape[0] <= cap
+            if not use or image.shape[0] > cap:
                 if pending is not None:
                     yield hand_over(pending)
                     pending = None
@@ -531,7 +550,7 @@ class CustomCLIP:
             if not stable_inputs:                        # (the previous user of this staging buffer, batch k - 2, was handed over already:
                 buf = self._overlap_staging[k & 1]       #  the current stream is ordered behind it)
                 if buf is None or buf.shape[1:] != image.shape[1:] or buf.shape[0] < image.shape[0] or buf.dtype != image.dtype:
-                    buf = self._overlap_staging[k & 1] = torch.empty((self.OVERLAP_MAX_BATCH,) + tuple(image.shape[1:]),
+                    buf = self._overlap_staging[k & 1] = torch.empty((cap,) + tuple(image.shape[1:]),
                                                                      dtype=image.dtype, device=self.device)
                 staged = buf[:image.shape[0]]
                 staged.copy_(image)

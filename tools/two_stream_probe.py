@@ -16,9 +16,10 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=256)
 ap.add_argument("--n", type=int, default=16)
 ap.add_argument("--reps", type=int, default=5)
+ap.add_argument("--model", default="ViT-B/16")
 args = ap.parse_args()
 dev = torch.device("cuda:0")
-spec = synth.SPECS["ViT-B/16"]
+spec = synth.SPECS[args.model]
 gen = torch.Generator(device=dev).manual_seed(1234)
 sd = bench.device_clip_state(spec, gen, dev)
 pl = bench.device_pl_state(spec, 2, gen, dev)
@@ -28,7 +29,8 @@ for _ in range(2):
     e.load_state_dict(sd, pl)
     e.finalize(args.batch, 256, 1024)
     engines.append(e)
-img = torch.randn((args.n * args.batch, 3, 224, 224), device=dev).half()
+R = spec.image_resolution
+img = torch.randn((args.n * args.batch, 3, R, R), device=dev).half()
 outs = [torch.empty((args.batch, spec.embed_dim), dtype=torch.float16, device=dev) for _ in range(2)]
 streams = [torch.cuda.Stream(), torch.cuda.Stream()]
 
@@ -56,4 +58,5 @@ for name, fn in (("one_stream", one), ("two_streams", two), ("one_stream_again",
 # same results from both engines
 engines[0].encode_image(img[:args.batch], out=outs[0]); engines[1].encode_image(img[:args.batch], out=outs[1]); torch.cuda.synchronize()
 res["bit_equal_engines"] = bool(torch.equal(outs[0], outs[1]))
+res["model"], res["batch"] = args.model, args.batch
 print(json.dumps(res))
