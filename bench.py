@@ -152,6 +152,8 @@ def main():
     loader = ResidentEvalSet(ex_img, torch.arange(c0, c1, device=dev), S, args.classes_per_batch, presharded=True)
 
     infer_only = PRESETS[args.preset].get("value") == "inference"    # c3: the classifiers are set-up, the step is the query loop
+    if args.overlap == 1 or (args.overlap < 0 and args.query_batch <= model.OVERLAP_MAX_BATCH):
+        model._twin()                                   # set-up, like the first handle's: the second handle forward_batches uses (not part of a step)
 
     def generate():
         if not sharded:
