@@ -209,6 +209,11 @@ def main():
     images_per_step = Q if infer_only else C * S + Q
     value = images_per_step * args.steps / dt
     roof = measure_roofline(eng, spec, args, dev, 0 if infer_only else (c1 - c0) * S, q1 - q0) if rank == 0 else None
+    if roof is not None and (args.overlap == 1 or (args.overlap < 0 and args.query_batch <= model.OVERLAP_MAX_BATCH)) and q1 > q0:
+        roof["launches_alone_note"] = ("every shape is timed with its launches running ALONE; in the job the query-batch launches (M = "
+                                       f"{args.query_batch * spec.vision_tokens}) run two at a time (forward_batches), so a profiler's per-kernel-name "
+                                       "average also holds durations of overlapped pairs -- per launch shape: tools/dominant_by_grid.py, "
+                                       "profiles/*_dominant_kernel_by_grid.json")
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(spec, sd, pl, tok, args, n_ctx) if args.cpu_sample_classes > 0 else None   # 0: profiling runs skip the CPU leg

@@ -19,6 +19,7 @@ timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_ou
 cd $R
 f=$(find gpurun_out/${T}_stats -name "*kernel_stats.csv" | head -1); cp $f profiles/${T}_rocprofv3_kernel_stats_bench_full.csv; head -6 $f | cut -c1-200
 grep '^{"metric' gpurun_out/${T}_stats_bench.log > profiles/${T}_bench_under_rocprof.json
+python3 tools/dominant_by_grid.py $(find gpurun_out/${T}_stats -name "*kernel_trace.csv" | head -1) profiles/${T}_bench_under_rocprof.json profiles/${T}_dominant_kernel_by_grid.json > /dev/null
 mkdir -p gpurun_out/${T}_keep; cp profiles/${T}_* gpurun_out/${T}_keep/     # gpurun merges only gpurun_out/ back: copy gpurun_out/<tag>_keep/* into profiles/ afterwards
 python3 - <<PY
 import json
