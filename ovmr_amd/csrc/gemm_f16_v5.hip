@@ -219,15 +219,27 @@ __global__ __launch_bounds__(512) void gemm_f16_v5_kernel(GemmArgs a, int tiles_
             sa8[hf][j] = src_off(a.a_blocked ? ra : min(ra, a.M - 1), a.lda, a.a_blocked);
             sb8[hf][j] = src_off(a.w_blocked ? rb : min(rb, a.N - 1), a.ldw, a.w_blocked);
         }
+    const unsigned smem_lds = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lptr_t)smem);
+    const unsigned wave_lds = (unsigned)__builtin_amdgcn_readfirstlane(wave * 2048);
     auto stage_half = [&](int buf, int which, int kt) {
-        char* base = smem + buf * KBUF + which * SLOT + wave * 2048;
         const int hf = which >> 1;
+        // LDS-DMA as scalar base (the K-tile's) + 32-bit lane offset, from inline asm: hipcc turns the builtin's address into a 64-bit
+        // vector add per instruction (v_lshl_add_u64) and the LDS address into two v_readfirstlane -- vector-port instructions of the
+        // loading row beside the other row's MFMAs.  Here a DMA instruction costs scalar instructions only (r03w, same-process A/B at
+        // M = 151 296: qkv 479 -> 468 us, c_fc 698 -> 691, c_proj 582 -> 578, K loop alone +0.6-1.3 %).  The compiler does not see these
+        // loads: every wait for them is one of the counted s_waitcnt of the loop (tests/test_isa_sync_templates.py).
+        const char* ak = (const char*)A + (long)kt * a_step;
+        const char* wk = (const char*)W + (long)kt * w_step;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            if (which & 1)
-                __builtin_amdgcn_global_load_lds((gptr_t)((const char*)A + sa8[hf][j] + (long)kt * a_step), (lptr_t)(base + j * 1024), 16, 0, (OPT & 1) ? 2 : 0);
-            else
-                __builtin_amdgcn_global_load_lds((gptr_t)((const char*)W + sb8[hf][j] + (long)kt * w_step), (lptr_t)(base + j * 1024), 16, 0, (OPT & 2) ? 2 : 0);
+            const unsigned dst = smem_lds + (unsigned)(buf * KBUF + which * SLOT + j * 1024) + wave_lds;   // scalar arithmetic only
+            if (which & 1) {
+                if constexpr ((OPT & 1) != 0) asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 nt" :: "v"(sa8[hf][j]), "s"(ak), "s"(dst) : "memory", "m0");
+                else asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(sa8[hf][j]), "s"(ak), "s"(dst) : "memory", "m0");
+            } else {
+                if constexpr ((OPT & 2) != 0) asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 nt" :: "v"(sb8[hf][j]), "s"(wk), "s"(dst) : "memory", "m0");
+                else asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(sb8[hf][j]), "s"(wk), "s"(dst) : "memory", "m0");
+            }
         }
     };
     const int a_lane = (wm * 64 + fr) * 128, b_lane = (wn * 32 + fr) * 128;

@@ -85,3 +85,8 @@ def test_gemm_ping_pong_loop_keeps_only_the_counted_waits():
         # of the first MFMA); nothing else -- in particular no other count, which would be a wait hipcc computed for loads of its own
         assert waits and all(re.fullmatch(r"s_waitcnt vmcnt\((4|0)\)( lgkmcnt\(\d+\))?", w) for w in waits), f"{name}: {sorted(set(waits))}"
         assert any("vmcnt(4)" in w for w in waits), f"{name}: the counted wait is gone: {waits}"
+        # the LDS-DMA of the loop is issued with scalar instructions only (scalar base + 32-bit lane offset, M0 from a scalar add):
+        # no 64-bit vector address add and no v_readfirstlane per instruction beside the other row's MFMAs
+        dma = [t for t in body if t.startswith("global_load_lds_dwordx4")]
+        assert dma and all(re.match(r"global_load_lds_dwordx4 v\d+, s\[\d+:\d+\]", t) for t in dma), f"{name}: {sorted(set(dma))[:3]}"
+        assert not any(t.startswith(("v_lshl_add_u64", "v_readfirstlane")) for t in body), f"{name}: vector address arithmetic in the K loop"
