@@ -523,8 +523,6 @@ class CustomCLIP:
                 raise NotImplementedError("pass eval_set_loader= to generate the classifiers")
             self.forward_prompt(eval_set_loader)
         cur = torch.cuda.current_stream(self.device)
-        pending = None                                   # (output, event on its stream)
-        k = 0
 
         def hand_over(p):
             out, ev = p
@@ -533,6 +531,15 @@ class CustomCLIP:
             return out
 
         cap = min(self.OVERLAP_MAX_BATCH, getattr(self.engine, "_reserve", (256,))[0])    # what the twin's workspace holds
+        try:
+            yield from self._forward_batches(batches, overlap, stable_inputs, cap, cur, hand_over)
+        finally:                                         # also when the caller abandons the loop: later work on the caller's stream
+            for st in getattr(self, "_overlap_streams", ()):     # (another forward on the first handle) is ordered behind what is in flight
+                cur.wait_stream(st)
+
+    def _forward_batches(self, batches, overlap, stable_inputs, cap, cur, hand_over):
+        pending = None                                   # (output, event on its stream)
+        k = 0
         for image in batches:
             image = self.engine._dev(image)
             use = overlap if overlap is not None else image.shape[0] <= cap

@@ -285,6 +285,12 @@ def test_forward_batches_equals_forward_with_two_batches_in_flight(tmp_path):
     got = [o.clone() for o in model.forward_batches(iter(seq))]
     assert torch.equal(got[0], want[0]) and torch.equal(got[1], model(big)) and torch.equal(got[2], want[1])
 
+    it = model.forward_batches(iter(chunks), stable_inputs=True)               # an abandoned loop: what is in flight is ordered in front of
+    first = next(it).clone()                                                   # the next use of the handles on the caller's stream
+    next(it)
+    it.close()
+    assert torch.equal(first, want[0]) and torch.equal(model(chunks[3]), want[3]) and torch.equal(model(chunks[0]), want[0])
+
     model.engine.set_option("gelu_exact", 1)                                   # the twin mirrors the options of the first handle ...
     want_exact = [model(c).clone() for c in chunks[:3]]
     got = [o.clone() for o in model.forward_batches(iter(chunks[:3]))]
