@@ -61,6 +61,7 @@ def parse():
                     help="exemplar images per encoder launch sequence (768 x 197 rows = 591 row tiles: 6.9 / 20.8 / 27.7 rounds of 256 CUs "
                          "for the N = 768 / 2304 / 3072 GEMMs; 512 gives 4.6 rounds on N = 768, i.e. 8 % idle in the fifth)")
     ap.add_argument("--query-batch", type=int, default=256, help="query images per inference call (256 = BASELINE config 3)")
+    ap.add_argument("--fuse-im2col", type=int, default=1, help="patch rows gathered inside the patch-embedding GEMM (1) or written out by an im2col pass first (0)")
     ap.add_argument("--overlap", type=int, default=-1, help="two query batches in flight on two streams (CustomCLIP.forward_batches): "
                     "1 / 0 force it on / off, -1 = the module's rule (batches of at most 384 images)")
     ap.add_argument("--classes-per-batch", type=int, default=240, help="classes per loader batch (x shots = a multiple of --batch)")
@@ -137,6 +138,7 @@ def main():
                                reserve=(args.batch, max(256, min(C, 2048)), max(C, 1024)), distributed=sharded)
     eng = model.engine
     eng.set_option("gelu_exact", args.gelu_exact)
+    eng.set_option("fuse_im2col", args.fuse_im2col)
     eng.set_option("gemm", args.gemm)
     eng.set_option("attn", args.attn)
     eng.set_option("ln_fold", args.ln_fold)

@@ -62,7 +62,7 @@ void ovmr_destroy(ovmr_handle* h);
 const char* ovmr_last_error(const ovmr_handle* h);
 const char* ovmr_version(void);
 
-/* Kernel-variant switch used by tests/bench to A/B implementations: key in {"gemm","attn","ln_fold","xval_fused","gelu_exact"}.
+/* Kernel-variant switch used by tests/bench to A/B implementations: key in {"gemm","attn","ln_fold","xval_fused","gelu_exact","fuse_im2col"}.
  * "gemm" (default 8): 8 = 256-row LDS-DMA tiles with the ping-pong K loop (half-tile staging, counted waits), 6 = the same tiles with the double-buffered
  *   K loop, 0 = the 128x128 register-staged kernel everywhere (LayerNorm-folding and fused-argmax launches still take the tile kernel).
  * "attn" (default 3): 3 = single-pass persistent kernel where the shape is its own (non-causal, 192 < L <= 208), the 32x32x16 flash
@@ -76,7 +76,9 @@ const char* ovmr_version(void);
  * "gelu_exact" (default 0): QuickGELU of the c_fc epilogue (clip/model.py:162-164).  1 keeps the three fp16 rounding points of the
  *   reference's fp16 tensors (h(1.702 u), h(sigmoid), h(u s)); 0 evaluates x / (1 + exp(-1.702 x)) in fp32 on the unrounded
  *   linear output and rounds once -- closer to the real function, within a few fp16 steps of the reference's value, and 5 % off
- *   the c_fc launch. */
+ *   the c_fc launch.
+ * "fuse_im2col" (default 1): conv1 on fp16 images with 16 x 16 patches -- the patch-embedding GEMM gathers its A rows from the image
+ *   tensor inside its K loop; 0 writes the patch matrix out first (what fp32 images and other patch sizes always do).  Bit-identical. */
 int ovmr_set_option(ovmr_handle* h, const char* key, int value);
 
 /* Weight ingestion -- replaces build_model()/convert_weights()/load_state_dict

@@ -57,6 +57,9 @@ struct GemmArgs {
     int nt_store;                          // v5: 0 = auto (streaming stores when C is much larger than the L2s), 1 = never, 2 = always
     float* argmax_out;                     // EPI_SCALE_ARGMAX: [M][ceil(N/256)][2] (value, column index bits)
     int gelu_mode;                         // QuickGELU epilogues: 0 = the reference's three fp16 rounding points, 1 = quick_gelu_f32x2 (set from variant / 100)
+    // EPI_PATCH, gemm_f16_v5 only: A is the fp16 IMAGE tensor [B, 3, R, R] itself and the K loop gathers the patch rows
+    // (k = c * 256 + ky * 16 + kx, 16 x 16 patches) straight into LDS -- no im2col pass.  0 = A is the [M, K] matrix.
+    int im2col_R;
 };
 
 __device__ __forceinline__ float quick_gelu_h(float u) {

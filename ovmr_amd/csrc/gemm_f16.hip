@@ -142,6 +142,10 @@ int launch_gemm_f16(const GemmArgs& a_in, int variant, hipStream_t s) {
     if (a.M <= 0 || a.N <= 0) return 0;
     if (a.K <= 0 || (a.K % BK) != 0 || (a.lda & 7) || (a.ldw & 7)) return -2;  // caller pads K to 64
     const int v5 = variant == 0 ? 8 : variant;
+    if (a.im2col_R) {                                                           // only the v5 kernel gathers patch rows from the image; -4: shape not supported
+        const int rc = launch_gemm_f16_v5(a, v5, s);
+        return rc == -100 ? -4 : rc;
+    }
     if (a.epi == EPI_SCALE_ARGMAX) {                                            // only the v5 kernel; -4: shape not supported
         const int rc = launch_gemm_f16_v5(a, v5, s);
         return rc == -100 ? -4 : rc;

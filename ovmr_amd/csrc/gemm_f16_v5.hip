@@ -111,10 +111,27 @@ __global__ __launch_bounds__(512) void gemm_f16_v5_kernel(GemmArgs a, int tiles_
         return blocked ? (unsigned)(((long)(row >> 7) * nk) * 16384 + (row & 127) * 128 + schunk * 2)
                        : (unsigned)(((long)row * ld + schunk) * 2);
     };
+    // EPI_PATCH with a.im2col_R: the A operand is the image tensor [B, 3, R, R] (fp16) and row r = patch (b, gy, gx) of the 16 x 16
+    // grid cells.  K-tile kt holds k = kt*64 .. +63 = channel kt >> 2, pixel rows 4 (kt & 3) .. +3 of the patch, 16 pixels each: the
+    // 16-byte chunk c8 of a row is pixel row c8 >> 1, pixels 8 (c8 & 1) .. +7.  So a lane's source is (row part + chunk part) + a
+    // K-tile part that is the same for every lane -- exactly the scalar-base + lane-offset form of the DMA.
+    const int imR = (EPI == EPI_PATCH) ? a.im2col_R : 0;
+    auto a_off = [&](int row) -> unsigned {
+        if (EPI == EPI_PATCH && imR) {
+            const int G = imR >> 4, r = min(row, a.M - 1), b = r / a.rows_in, p = r - b * a.rows_in, gy = p / G, gx = p - gy * G;
+            const int c8 = schunk >> 3;
+            return (unsigned)(2 * (((long)b * 3 * imR + gy * 16 + (c8 >> 1)) * imR + gx * 16 + (c8 & 1) * 8));
+        }
+        return src_off(a.a_blocked ? row : min(row, a.M - 1), a.lda, a.a_blocked);
+    };
+    auto a_tile = [&](int kt) -> const char* {           // wave-uniform
+        if (EPI == EPI_PATCH && imR) return (const char*)A + 2 * ((long)(kt >> 2) * imR * imR + (kt & 3) * 4 * imR);
+        return (const char*)A + (long)kt * a_step;
+    };
 #pragma unroll
     for (int j = 0; j < AJ; ++j) {
         const int r = m0 + wave * (BM / 8) + j * 8 + srow;
-        oa[j] = src_off(a.a_blocked ? r : min(r, a.M - 1), a.lda, a.a_blocked);
+        oa[j] = a_off(r);
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -128,7 +145,7 @@ __global__ __launch_bounds__(512) void gemm_f16_v5_kernel(GemmArgs a, int tiles_
         char* base = smem + buf * STAGE;
 #pragma unroll
         for (int j = 0; j < AJ; ++j)
-            __builtin_amdgcn_global_load_lds((gptr_t)((const char*)A + oa[j] + (long)kt * a_step), (lptr_t)(base + ldsA_w + j * 1024), 16, 0, (OPT & 1) ? 2 : 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(a_tile(kt) + oa[j]), (lptr_t)(base + ldsA_w + j * 1024), 16, 0, (OPT & 1) ? 2 : 0);
 #pragma unroll
         for (int j = 0; j < 4; ++j)
             __builtin_amdgcn_global_load_lds((gptr_t)((const char*)W + ob[j] + (long)kt * w_step), (lptr_t)(base + ldsB_w + j * 1024), 16, 0, (OPT & 2) ? 2 : 0);
@@ -216,7 +233,7 @@ __global__ __launch_bounds__(512) void gemm_f16_v5_kernel(GemmArgs a, int tiles_
             const int lr = wave * 16 + j * 8 + srow;                                    // local row inside the half-tile
             const int ra = m0 + (lr >> 6) * 128 + hf * 64 + (lr & 63);
             const int rb = n0 + (lr >> 5) * 64 + hf * 32 + (lr & 31);
-            sa8[hf][j] = src_off(a.a_blocked ? ra : min(ra, a.M - 1), a.lda, a.a_blocked);
+            sa8[hf][j] = a_off(ra);
             sb8[hf][j] = src_off(a.w_blocked ? rb : min(rb, a.N - 1), a.ldw, a.w_blocked);
         }
     const unsigned smem_lds = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lptr_t)smem);
@@ -228,7 +245,7 @@ __global__ __launch_bounds__(512) void gemm_f16_v5_kernel(GemmArgs a, int tiles_
         // loading row beside the other row's MFMAs.  Here a DMA instruction costs scalar instructions only (r03w, same-process A/B at
         // M = 151 296: qkv 479 -> 468 us, c_fc 698 -> 691, c_proj 582 -> 578, K loop alone +0.6-1.3 %).  The compiler does not see these
         // loads: every wait for them is one of the counted s_waitcnt of the loop (tests/test_isa_sync_templates.py).
-        const char* ak = (const char*)A + (long)kt * a_step;
+        const char* ak = a_tile(kt);
         const char* wk = (const char*)W + (long)kt * w_step;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -911,6 +928,12 @@ int launch_gemm_f16_v5(const GemmArgs& a, int variant, hipStream_t s) {
         ((uintptr_t)a.C & 15) || (a.epi == EPI_BIAS_RES && ((uintptr_t)a.res & 15)) ||
         (long)a.M * a.lda * 2 >= 0x7fffffffL || (long)a.N * a.ldw * 2 >= 0x7fffffffL)
         return -100;
+    if (a.im2col_R) {                                  // A = fp16 images [B, 3, R, R], 16 x 16 patches: K = 768, byte offsets in 32 bits
+        const int G = a.im2col_R >> 4;
+        if (a.epi != EPI_PATCH || a.K != 768 || (a.im2col_R & 15) || a.rows_in != G * G || ((uintptr_t)a.A & 15) ||
+            (long)((a.M + a.rows_in - 1) / a.rows_in) * 3 * a.im2col_R * a.im2col_R * 2 >= 0xffffffffL)
+            return -2;
+    }
     const bool lnf = a.epi == EPI_LN_BIAS || a.epi == EPI_LN_BIAS_QGELU;
     if (lnf && ((a.N & 63) || !a.ln_stats || a.ln_slots < 1 || !a.ln_g || !a.ln_b)) return -2;
     if (a.stats_out && (a.epi != EPI_BIAS_RES || (a.N & 255))) return -2;

@@ -40,7 +40,8 @@ struct ovmr_handle {
     std::vector<void*> derived;   // layouts rebuilt by every ovmr_finalize
     std::string err;
     bool finalized = false;
-    int gelu_exact = 0;                       // 0: one-rounding fp32 QuickGELU in the c_fc epilogue (common.h quick_gelu_f32x2); 1: the reference's three fp16 rounding points
+    int gelu_exact = 0;
+    int fuse_im2col = 1;          // patch rows gathered by the patch-embedding GEMM itself (fp16 images, 16 x 16 patches)                       // 0: one-rounding fp32 QuickGELU in the c_fc epilogue (common.h quick_gelu_f32x2); 1: the reference's three fp16 rounding points
     int gemm_variant = 8, attn_variant = 3;   // defaults = fastest verified kernels (tools/gemm_bench.py, tools/attn_bench.py); attention 3 falls back to 1 / 0 by shape
     int ln_fold = 1;                          // fold ln_1 / ln_2 of the fp16 towers into the consuming GEMM where the shape allows
     int xval_fused = 1;                       // cross-validation logits: row argmax fused into the GEMM epilogue (never stored)
@@ -274,6 +275,7 @@ int ovmr_set_option(ovmr_handle* h, const char* key, int value) {
     if (!h || !key) return OVMR_E_ARG;
     if (!strcmp(key, "gemm")) h->gemm_variant = value;
     else if (!strcmp(key, "attn")) h->attn_variant = value;
+    else if (!strcmp(key, "fuse_im2col")) h->fuse_im2col = value != 0;
     else if (!strcmp(key, "ln_fold")) h->ln_fold = value;
     else if (!strcmp(key, "xval_fused")) h->xval_fused = value;
     else if (!strcmp(key, "gelu_exact")) h->gelu_exact = value;
@@ -448,8 +450,16 @@ int ovmr_encode_image(ovmr_handle* h, const void* image, int image_dtype, int B,
         float* stats_buf = c.take<float>((size_t)M * ((W + 255) / 256) * 2);
         half_t* out = (half_t*)out_f16 + (size_t)b0 * E;
         // K1/K2: conv1 as GEMM over patches, positional add in the epilogue, CLS row, ln_pre
-        CK(launch_im2col((const char*)image + (size_t)b0 * px, image_dtype == OVMR_F32, col, Bc, R, d.vision_patch_size, h->Kpad, s));
+        // fp16 images with 16 x 16 patches: the GEMM's K loop gathers the patch rows from the image itself (gemm_f16_v5.hip, a.im2col_R);
+        // otherwise (fp32 images, other patch sizes, a handful of rows, the 128 x 128 kernel) an im2col pass writes them out first
+        const bool fused_patches = h->fuse_im2col && image_dtype == OVMR_F16 && d.vision_patch_size == 16 && h->Kpad == 768 && (R & 15) == 0 &&
+                                   Bc * G2 >= 256 && W >= 128 && h->gemm_variant >= 1 && ((uintptr_t)image & 15) == 0;
         GemmArgs pe = gemm(col, h->Kpad, h->conv_w, h->Kpad, x, W, Bc * G2, W, h->Kpad, EPI_PATCH);
+        if (fused_patches) {
+            pe.A = (const char*)image + (size_t)b0 * px;
+            pe.im2col_R = R;
+        } else
+            CK(launch_im2col((const char*)image + (size_t)b0 * px, image_dtype == OVMR_F32, col, Bc, R, d.vision_patch_size, h->Kpad, s));
         pe.pos = h->pos16_vis; pe.rows_in = G2; pe.rows_out = L;
         CK(launch_gemm_f16(pe, h->gemm_variant, s));
         CK(launch_fill_cls(x, h->cls_pos16, Bc, L, W, s));

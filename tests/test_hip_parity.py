@@ -57,6 +57,29 @@ def test_encode_image_vs_golden(golden, name, key, n_img):
         assert_cosine(f, g["l1_fp32_image_features"], COS_TOL, "image features vs reference fp32 path")
 
 
+@pytest.mark.parametrize("name,n_img", [("tiny", 64), ("tiny", 49), ("small", 16), ("small", 35), ("ViT-B/16", 3)])
+def test_patch_rows_gathered_by_the_gemm_equal_the_im2col_pass(name, n_img):
+    """conv1 (clip/model.py:366, 412-414) as a GEMM over 16 x 16 patches: with fp16 images the K loop of the patch-embedding GEMM
+    gathers the patch rows from the image tensor itself (GemmArgs::im2col_R, option fuse_im2col = 1, the default); the features must be
+    bit-equal to the path that writes the patch matrix out first (fuse_im2col = 0; also what fp32 images take).  Full and ragged row
+    tiles, 128- and 256-row tiles, odd image counts, an image tensor that starts at an offset inside a larger one."""
+    e = _clip(name).engine(2)
+    R = synth.SPECS[name].image_resolution
+    pool = torch.from_numpy(synth.images(n_img + 1, R, seed=77)).half().cuda()
+    img = pool[1:]                                                          # 16-byte aligned, not at the start of its allocation
+    try:
+        e.set_option("fuse_im2col", 0)
+        want = e.encode_image(img, normalize=False).clone()
+        want32 = e.encode_image(img.float(), normalize=False).clone()
+        e.set_option("fuse_im2col", 1)
+        got = e.encode_image(img, normalize=False).clone()
+        got32 = e.encode_image(img.float(), normalize=False).clone()
+    finally:
+        e.set_option("fuse_im2col", 1)
+    assert torch.equal(got, want) and torch.equal(got32, want32) and torch.equal(want, want32)
+    assert bool(torch.isfinite(got.float()).all())
+
+
 def test_quickgelu_forms_vs_golden(golden, capsys):
     """gelu_exact = 0 (default: one-rounding fp32 QuickGELU in the c_fc epilogue) and = 1 (the reference's three fp16 rounding points)
     against the reference's recorded ViT-B/16 features: BOTH stay under 1e-4 in 1 - cos, a 10x margin to the 1e-3 bar, against the
