@@ -62,7 +62,7 @@ def test_headline_config_bench_job_vs_oracle(O):
     from ovmr_amd import modules
     from ovmr_amd.data import ResidentEvalSet
     dev = torch.device("cuda:0")
-    spec, C, S, n_ctx, batch = synth.SPECS["ViT-B/16"], 1000, 16, 2, 768           # bench.py defaults: --batch 768, --classes-per-batch 240
+    spec, C, S, n_ctx, batch = synth.SPECS["ViT-B/16"], 1000, 16, 2, bench.DEFAULT_BATCH   # bench.py defaults: --batch 775, --classes-per-batch 1000
     gen = torch.Generator(device=dev).manual_seed(1234)
     sd = bench.device_clip_state(spec, gen, dev)
     pl = bench.device_pl_state(spec, n_ctx, gen, dev)
@@ -76,7 +76,7 @@ def test_headline_config_bench_job_vs_oracle(O):
     for s in range(0, C * S, 1024):
         ex[s:s + 1024] = torch.randn((min(1024, C * S - s), 3, R, R), generator=ig, device=dev).half()
     q = torch.randn((8, 3, R, R), generator=ig, device=dev).half()
-    loader = ResidentEvalSet(ex, torch.arange(C, device=dev), S, 240, presharded=True)
+    loader = ResidentEvalSet(ex, torch.arange(C, device=dev), S, bench.DEFAULT_CLASSES_PER_BATCH, presharded=True)
     mm, v, fw = model.forward_prompt(loader)
     out = model(q).cpu()
     t = model.zero_shot_classifier

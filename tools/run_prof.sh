@@ -9,7 +9,7 @@ if [ -z "$2" ]; then
   timeout 1800 python -m pytest tests -m gpu -x -q > gpurun_out/${T}_pytest.log 2>&1; tail -2 gpurun_out/${T}_pytest.log
   timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/${T}_smoke.log 2>&1; tail -1 gpurun_out/${T}_smoke.log
 fi
-bash tools/pmc_gemm.sh 108 gpurun_out/${T}_pmc_gemm 768 > gpurun_out/${T}_pmc_gemm.log 2>&1
+bash tools/pmc_gemm.sh 108 gpurun_out/${T}_pmc_gemm 775 > gpurun_out/${T}_pmc_gemm.log 2>&1
 cp gpurun_out/${T}_pmc_gemm/summary.json profiles/${T}_pmc_gemm_v108.json
 VARIANTS="1 3" bash tools/pmc_attn.sh gpurun_out/${T}_pmc_attn > gpurun_out/${T}_pmc_attn.log 2>&1
 cp gpurun_out/${T}_pmc_attn/summary.json profiles/${T}_pmc_attn.json
