@@ -44,7 +44,9 @@ PRESETS = {
     "c3": {"about": "ViT-B/16 fusion inference at batch 256 against 1000 x 16-shot classifiers; value = inference images/s",
            "set": {"queries": 16384}, "value": "inference"},
     "c5": {"about": "ViT-L/14@336px, 1000 classes x 32 shots + 512 queries (the MFMA-bound stress configuration)",
-           "set": {"model": "ViT-L/14@336px", "shots": 32, "queries": 512, "batch": 128, "query_batch": 128, "classes_per_batch": 128}},
+           # 170 images x 577 tokens = 384 row tiles: 6.0 / 18.0 / 24.0 rounds of the 256 CUs on the N = 1024 / 3072 / 4096 GEMMs (r03y: 2 917 img/s
+           # against 2 802 at 128 images and 128 classes per loader batch)
+           "set": {"model": "ViT-L/14@336px", "shots": 32, "queries": 512, "batch": 170, "query_batch": 128, "classes_per_batch": 1000}},
 }
 
 
