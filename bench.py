@@ -68,6 +68,8 @@ def parse():
                          "27.70, 512 gives 4.6 rounds on N = 768, i.e. 8 % idle in the fifth)")
     ap.add_argument("--query-batch", type=int, default=256, help="query images per inference call (256 = BASELINE config 3)")
     ap.add_argument("--fuse-im2col", type=int, default=1, help="patch rows gathered inside the patch-embedding GEMM (1) or written out by an im2col pass first (0)")
+    ap.add_argument("--enc-chunk", type=int, default=0, help="images per launch sequence of the image tower: 0 = the engine's choice (<= --batch, whole "
+                    "rounds of tiles: ovmr_encode_chunk), n pins it")
     ap.add_argument("--overlap", type=int, default=-1, help="two query batches in flight on two streams (CustomCLIP.forward_batches): "
                     "1 / 0 force it on / off, -1 = the module's rule (batches of at most 384 images)")
     ap.add_argument("--classes-per-batch", type=int, default=DEFAULT_CLASSES_PER_BATCH,
@@ -147,6 +149,7 @@ def main():
     eng = model.engine
     eng.set_option("gelu_exact", args.gelu_exact)
     eng.set_option("fuse_im2col", args.fuse_im2col)
+    eng.set_option("enc_chunk", args.enc_chunk)
     eng.set_option("gemm", args.gemm)
     eng.set_option("attn", args.attn)
     eng.set_option("ln_fold", args.ln_fold)
@@ -241,7 +244,7 @@ def main():
                        "parallelism": f"class/query sharding over {world} rank(s); all-gather rows + all-reduce counters"
                                       + (f" (process group {dist.get_backend()}, sharded path forced)" if args.force_dist and world == 1 else ""),
                        "preset": args.preset, "gemm_variant": args.gemm, "attn_variant": args.attn, "ln_fold": args.ln_fold, "gelu_exact": args.gelu_exact,
-                       "images_per_step": images_per_step},
+                       "encoder_reserve_images": args.batch, "encoder_chunk_images": eng.encode_chunk, "images_per_step": images_per_step},
             "roofline": roof,
             "cpu_baseline": cpu,
             "phases": {"generation_images_per_s_rank0": round((c1 - c0) * S / tg, 1),
@@ -330,14 +333,16 @@ def device_pl_state(spec, n_ctx, gen, dev):
     return sd
 
 
-def encoder_chunks(n_images, loader_batch, engine_batch):
+def encoder_chunks(n_images, loader_batch, engine_batch, reserve=None):
     """Image counts of the encoder launch sequences a stream of `n_images` produces: the loader hands over `loader_batch`
-    images at a time, the engine encodes them in chunks of at most `engine_batch` (ovmr_encode_image)."""
+    images at a time; what fits the engine's workspace (`reserve` images) is one launch sequence, a larger batch is encoded in
+    chunks of `engine_batch` (ovmr_encode_image / ovmr_encode_chunk)."""
     out = {}
     for s0 in range(0, n_images, loader_batch):
         n = min(loader_batch, n_images - s0)
-        for c0 in range(0, n, engine_batch):
-            b = min(engine_batch, n - c0)
+        step = n if (reserve is not None and n <= reserve) else engine_batch
+        for c0 in range(0, n, step):
+            b = min(step, n - c0)
             out[b] = out.get(b, 0) + 1
     return out
 
@@ -353,8 +358,10 @@ def measure_roofline(eng, spec, args, dev, n_exemplar_images, n_query_images):
     import torch
     lib = eng.lib
     N, K, L = 4 * spec.vision_width, spec.vision_width, spec.vision_tokens
-    chunks = encoder_chunks(n_exemplar_images, args.classes_per_batch * args.shots, args.batch)
-    for b, n in encoder_chunks(n_query_images, args.query_batch, args.batch).items():
+    chunk = eng.encode_chunk                            # images per launch sequence (<= --batch)
+    pinned = args.enc_chunk > 0
+    chunks = encoder_chunks(n_exemplar_images, args.classes_per_batch * args.shots, chunk, None if pinned else args.batch)
+    for b, n in encoder_chunks(n_query_images, args.query_batch, chunk, None if pinned else args.batch).items():
         chunks[b] = chunks.get(b, 0) + n
     layers = spec.vision_layers - 1                                   # the last block runs the CLS row only (other kernels)
     g = torch.Generator(device=dev).manual_seed(7)

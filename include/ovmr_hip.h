@@ -62,7 +62,7 @@ void ovmr_destroy(ovmr_handle* h);
 const char* ovmr_last_error(const ovmr_handle* h);
 const char* ovmr_version(void);
 
-/* Kernel-variant switch used by tests/bench to A/B implementations: key in {"gemm","attn","ln_fold","xval_fused","gelu_exact","fuse_im2col"}.
+/* Kernel-variant switch used by tests/bench to A/B implementations: key in {"gemm","attn","ln_fold","xval_fused","gelu_exact","fuse_im2col","enc_chunk"}.
  * "gemm" (default 8): 8 = 256-row LDS-DMA tiles with the ping-pong K loop (half-tile staging, counted waits), 6 = the same tiles with the double-buffered
  *   K loop, 0 = the 128x128 register-staged kernel everywhere (LayerNorm-folding and fused-argmax launches still take the tile kernel).
  * "attn" (default 3): 3 = single-pass persistent kernel where the shape is its own (non-causal, 192 < L <= 208), the 32x32x16 flash
@@ -164,6 +164,13 @@ float ovmr_logit_scale(const ovmr_handle* h);
  * centre-cropped images (the host's share of the transform); out_f16: fp16 [B, 3, R, R] = h(((u / 255) - mean[c]) / std[c]), the
  * fp32 arithmetic of torchvision bit for bit.  mean3 / std3 are HOST pointers to three floats.  R % 8 == 0.  Needs no handle. */
 int ovmr_preprocess_u8(const void* u8_hwc, int B, int R, const float* mean3, const float* std3, void* out_f16, ovmr_stream stream);
+
+/* Images per launch sequence of ovmr_encode_image after ovmr_finalize (<= max_images): a batch of MORE than max_images images is
+ * encoded in chunks of this many (one that fits the workspace is a single launch sequence), chosen so that the 256-row-tile grids of the block GEMMs are whole rounds of the CUs and no launch has more than 600 row tiles (ViT-B/16 on 256 CUs: 775 of a
+ * reserve of 775 or more, 665 of 768); ovmr_set_option(h, "enc_chunk", n) pins it (0 = automatic).  Chunks of at least 256
+ * token rows give bit-identical features; smaller ones take the small-matrix kernels (other rounding points, same tolerance).
+ * 0 before ovmr_finalize. */
+int ovmr_encode_chunk(const ovmr_handle* h);
 
 /* Closed-form FLOP counts.  ovmr_flops_per_image is the ALGORITHMIC count of the reference's
  * VisionTransformer.forward (every block over every token, clip/model.py:411-428: 35.127 GFLOP for ViT-B/16);

@@ -58,6 +58,9 @@ struct ovmr_handle {
     char* ws = nullptr;
     size_t ws_bytes = 0;
     int max_images = 0, max_prompts = 0, max_classes = 0;
+    int enc_chunk_forced = 0;     // option "enc_chunk": > 0 pins the chunk, 0 = pick_encode_chunk
+    int n_cu = 0;
+    int enc_chunk = 0;            // images per launch sequence of ovmr_encode_image (<= max_images; pick_encode_chunk); option "enc_chunk" overrides
     long agg_rows_cap = 0, logit_elems_cap = 0;
 };
 
@@ -271,11 +274,41 @@ void ovmr_destroy(ovmr_handle* h) {
 
 const char* ovmr_last_error(const ovmr_handle* h) { return h ? h->err.c_str() : "null handle"; }
 
+// Images per launch sequence of the image tower.  Every GEMM of a block runs 256-row tiles, one workgroup per CU at a time, so a launch
+// costs WHOLE rounds of the CUs: with t = ceil(B * L / 256) row tiles the N = W launches (out_proj, K = W; c_proj, K = 4W) pay
+// ceil(t * W/256 / CUs) rounds, in_proj ceil(3 t W/256 / CUs), c_fc ceil(4 t W/256 / CUs), a round's time being proportional to K.
+// The chunk is the B <= max_images with the most images per unit of that cost (ViT-B/16, 256 CUs: 775 images = 597 tiles = 6.996 /
+// 20.99 / 27.98 rounds where 768 pays 7 / 21 / 28 for 6.93 / 20.78 / 27.70; ViT-L/14@336px: 170 images = 384 tiles = 6.0 / 18.0 / 24.0)
+// -- measured +1.5-2 % end to end.  Reserves of less than two rounds keep max_images.  No more than 600 row
+// tiles per chunk: beyond that the A panels of a launch compete for the L2s (ViT-B/16: 998 and 1108 images per chunk ran 4-5 % slower
+// than 775, c_fc at 0.384-0.388 of peak instead of 0.41; ViT-L/14@336px: 227 images = 512 tiles slower than 170 = 384).
+static int pick_encode_chunk(int max_images, int L, int W, int n_cu) {
+    const long nw = std::max(1, W / 256);
+    auto tiles = [&](long b) { return (b * L + 255) / 256; };
+    auto rounds = [&](long wg) { return (wg + n_cu - 1) / n_cu; };
+    if (n_cu < 1 || tiles(max_images) * nw < 2L * n_cu) return max_images;
+    auto cost = [&](long b) { const long t = tiles(b); return 5 * rounds(t * nw) + rounds(3 * t * nw) + rounds(4 * t * nw); };
+    const int top = (int)std::min<long>(max_images, std::max<long>(1, 600L * 256 / L));
+    int best = top;
+    double best_rate = (double)top / (double)cost(top);
+    for (int b = top - 1; b >= std::max(1, top * 3 / 4); --b) {
+        const double r = (double)b / (double)cost(b);
+        if (r > best_rate * 1.002) { best_rate = r; best = b; }      // (a smaller chunk has to buy more than launch overheads cost)
+    }
+    return best;
+}
+
 int ovmr_set_option(ovmr_handle* h, const char* key, int value) {
     if (!h || !key) return OVMR_E_ARG;
     if (!strcmp(key, "gemm")) h->gemm_variant = value;
     else if (!strcmp(key, "attn")) h->attn_variant = value;
     else if (!strcmp(key, "fuse_im2col")) h->fuse_im2col = value != 0;
+    else if (!strcmp(key, "enc_chunk")) {
+        h->enc_chunk_forced = value > 0 ? value : 0;
+        if (h->finalized)
+            h->enc_chunk = h->enc_chunk_forced > 0 ? std::min(h->enc_chunk_forced, h->max_images)
+                                                   : pick_encode_chunk(h->max_images, h->L, (int)h->d.vision_width, h->n_cu);
+    }
     else if (!strcmp(key, "ln_fold")) h->ln_fold = value;
     else if (!strcmp(key, "xval_fused")) h->xval_fused = value;
     else if (!strcmp(key, "gelu_exact")) h->gelu_exact = value;
@@ -411,6 +444,12 @@ int ovmr_finalize(ovmr_handle* h, int max_images, int max_prompts, int max_class
 
     // workspace: one arena, re-carved by each entry point (calls on one handle are stream ordered)
     h->max_images = max_images; h->max_prompts = max_prompts; h->max_classes = max_classes;
+    {
+        int dev = 0;
+        HIP_CHECK_RET(hipGetDevice(&dev));
+        HIP_CHECK_RET(hipDeviceGetAttribute(&h->n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+        h->enc_chunk = h->enc_chunk_forced > 0 ? std::min(h->enc_chunk_forced, max_images) : pick_encode_chunk(max_images, h->L, (int)d.vision_width, h->n_cu);
+    }
     h->agg_rows_cap = (long)max_classes * (d.n_ctx + 32);
     h->logit_elems_cap = 32L << 20;
     size_t need = image_ws_bytes(h, max_images);
@@ -437,8 +476,11 @@ int ovmr_encode_image(ovmr_handle* h, const void* image, int image_dtype, int B,
     const ovmr_model_desc& d = h->d;
     const int W = d.vision_width, R = d.image_resolution, L = h->L, G2 = h->G * h->G, E = d.embed_dim;
     const size_t px = (size_t)3 * R * R * (image_dtype == OVMR_F32 ? 4 : 2);
-    for (int b0 = 0; b0 < B; b0 += h->max_images) {
-        const int Bc = std::min(h->max_images, B - b0);
+    // a batch that fits the workspace is ONE launch sequence; a larger one is split into chunks of enc_chunk images (pick_encode_chunk),
+    // unless the option pins the chunk
+    const int chunk = h->enc_chunk_forced > 0 ? h->enc_chunk : (B > h->max_images && h->enc_chunk > 0 ? h->enc_chunk : h->max_images);
+    for (int b0 = 0; b0 < B; b0 += chunk) {
+        const int Bc = std::min(chunk, B - b0);
         const int M = Bc * L;
         Carver c(h->ws);
         half_t* col = c.take<half_t>((size_t)Bc * G2 * h->Kpad);
@@ -688,6 +730,8 @@ int ovmr_zeroshot_logits(ovmr_handle* h, const void* feats_f16, int B, const voi
 
 // Closed-form FLOPs (2*MAC), SURVEY.md section 2.3: per layer 24*L*W^2 (QKV 6, out 2, MLP 16) + 4*L^2*W
 static double tower_flops(double L, double W, double layers) { return layers * (24.0 * L * W * W + 4.0 * L * L * W); }
+
+int ovmr_encode_chunk(const ovmr_handle* h) { return h && h->finalized ? (h->enc_chunk > 0 ? h->enc_chunk : h->max_images) : 0; }
 
 double ovmr_flops_per_image(const ovmr_handle* h) {
     if (!h) return 0;

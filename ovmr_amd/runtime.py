@@ -52,6 +52,7 @@ SIGNATURES = {
     "ovmr_zeroshot_logits": (c_i, [c_p, c_p, c_i, c_p, c_i, c_p, c_p]),
     "ovmr_logit_scale": (ctypes.c_float, [c_p]),
     "ovmr_preprocess_u8": (c_i, [c_p, c_i, c_i, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float), c_p, c_p]),
+    "ovmr_encode_chunk": (ctypes.c_int, [c_p]),
     "ovmr_flops_per_image": (ctypes.c_double, [c_p]),
     "ovmr_flops_per_image_executed": (ctypes.c_double, [c_p]),
     "ovmr_flops_per_prompt": (ctypes.c_double, [c_p, c_i]),
@@ -178,6 +179,11 @@ class Engine:
     @property
     def logit_scale(self) -> float:
         return float(self.lib.ovmr_logit_scale(self.h))
+
+    @property
+    def encode_chunk(self) -> int:
+        """Images per launch sequence of encode_image (chosen by ovmr_finalize so that the GEMM grids are whole rounds of the CUs)."""
+        return int(self.lib.ovmr_encode_chunk(self.h))
 
     def flops_per_image(self) -> float:
         return float(self.lib.ovmr_flops_per_image(self.h))

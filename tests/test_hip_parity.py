@@ -776,3 +776,39 @@ def test_xval_fused_argmax_equals_materialised_logits(C, R, D_name):
     assert int(out[1][1].sum()) == R
     assert torch.equal(out[0], out[1])
     assert int(out[1][1][C - 1]) == 0 or C - 1 == 1        # the duplicate of row 1 never wins a tie
+
+
+def test_encoder_chunk_is_whole_rounds_and_does_not_change_results():
+    """ovmr_encode_chunk: the image tower encodes a batch in chunks chosen so that the 256-row-tile grids of the block GEMMs are whole
+    rounds of the CUs (ViT-B/16 on the 256 CUs of an MI355X: 775 of a reserve of 775 or 1024, 665 of a reserve of 768); chunks that
+    take the same kernels give the same features bit for bit (rows are independent), and the option pins it."""
+    from ovmr_amd import modules
+    spec = synth.SPECS["ViT-B/16"]
+    e = _clip("ViT-B/16").engine(2)
+    n_cu = torch.cuda.get_device_properties(0).multi_processor_count
+    try:
+        e.finalize(775, 64, 256)
+        auto775 = e.encode_chunk
+        e.finalize(768, 64, 256)
+        auto768 = e.encode_chunk
+        e.finalize(1024, 64, 256)
+        auto1024 = e.encode_chunk
+        if n_cu == 256:
+            assert (auto775, auto768, auto1024) == (775, 665, 775)
+        assert 768 * 3 // 4 <= auto768 <= 768
+        e.finalize(64, 64, 256)
+        assert e.encode_chunk == 64                                             # a reserve of less than two rounds is left alone
+        e.finalize(4, 64, 256)                                                  # 8 images against a workspace of 4: two launch sequences
+        img = torch.from_numpy(synth.images(8, spec.image_resolution, seed=5)).half().cuda()
+        want = e.encode_image(img, normalize=False).clone()
+        for c in (2, 4):                                                        # (chunks of >= 256 token rows: the same kernels as the whole batch)
+            e.set_option("enc_chunk", c)
+            assert e.encode_chunk == c
+            assert torch.equal(e.encode_image(img, normalize=False), want)
+        e.set_option("enc_chunk", 1)                                            # 197 rows: the small-matrix kernels, separate LayerNorm -- other roundings
+        assert_cosine(e.encode_image(img, normalize=False).float().cpu().numpy(), want.float().cpu().numpy(), COS_TOL, "chunks of one image")
+        e.set_option("enc_chunk", 0)
+        assert e.encode_chunk == 4
+    finally:
+        e.set_option("enc_chunk", 0)
+        e.finalize(64, 64, 256)
