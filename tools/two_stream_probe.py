@@ -17,6 +17,7 @@ ap.add_argument("--batch", type=int, default=256)
 ap.add_argument("--n", type=int, default=16)
 ap.add_argument("--reps", type=int, default=5)
 ap.add_argument("--model", default="ViT-B/16")
+ap.add_argument("--streams", type=int, default=2, help="engines / streams for the multi-stream leg")
 args = ap.parse_args()
 dev = torch.device("cuda:0")
 spec = synth.SPECS[args.model]
@@ -24,15 +25,15 @@ gen = torch.Generator(device=dev).manual_seed(1234)
 sd = bench.device_clip_state(spec, gen, dev)
 pl = bench.device_pl_state(spec, 2, gen, dev)
 engines = []
-for _ in range(2):
+for _ in range(args.streams):
     e = Engine(spec, 2, "cuda:0")
     e.load_state_dict(sd, pl)
     e.finalize(args.batch, 256, 1024)
     engines.append(e)
 R = spec.image_resolution
 img = torch.randn((args.n * args.batch, 3, R, R), device=dev).half()
-outs = [torch.empty((args.batch, spec.embed_dim), dtype=torch.float16, device=dev) for _ in range(2)]
-streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+outs = [torch.empty((args.batch, spec.embed_dim), dtype=torch.float16, device=dev) for _ in range(args.streams)]
+streams = [torch.cuda.Stream() for _ in range(args.streams)]
 
 def one():
     for b in range(args.n):
@@ -43,8 +44,9 @@ def two():
     for s in streams:
         s.wait_stream(cur)
     for b in range(args.n):
-        with torch.cuda.stream(streams[b & 1]):
-            engines[b & 1].encode_image(img[b * args.batch:(b + 1) * args.batch], out=outs[b & 1])
+        k = b % args.streams
+        with torch.cuda.stream(streams[k]):
+            engines[k].encode_image(img[b * args.batch:(b + 1) * args.batch], out=outs[k])
     for s in streams:
         cur.wait_stream(s)
 
@@ -58,5 +60,5 @@ for name, fn in (("one_stream", one), ("two_streams", two), ("one_stream_again",
 # same results from both engines
 engines[0].encode_image(img[:args.batch], out=outs[0]); engines[1].encode_image(img[:args.batch], out=outs[1]); torch.cuda.synchronize()
 res["bit_equal_engines"] = bool(torch.equal(outs[0], outs[1]))
-res["model"], res["batch"] = args.model, args.batch
+res["model"], res["batch"], res["streams"] = args.model, args.batch, args.streams
 print(json.dumps(res))
