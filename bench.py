@@ -68,6 +68,7 @@ def parse():
                          "27.70, 512 gives 4.6 rounds on N = 768, i.e. 8 % idle in the fifth)")
     ap.add_argument("--query-batch", type=int, default=256, help="query images per inference call (256 = BASELINE config 3)")
     ap.add_argument("--fuse-im2col", type=int, default=1, help="patch rows gathered inside the patch-embedding GEMM (1) or written out by an im2col pass first (0)")
+    ap.add_argument("--last-q-cls", type=int, default=1, help="last vision block: Q projected for the CLS rows only (1) or for every token (0)")
     ap.add_argument("--enc-chunk", type=int, default=0, help="images per launch sequence of the image tower: 0 = the engine's choice (<= --batch, whole "
                     "rounds of tiles: ovmr_encode_chunk), n pins it")
     ap.add_argument("--overlap", type=int, default=-1, help="two query batches in flight on two streams (CustomCLIP.forward_batches): "
@@ -150,6 +151,7 @@ def main():
     eng.set_option("gelu_exact", args.gelu_exact)
     eng.set_option("fuse_im2col", args.fuse_im2col)
     eng.set_option("enc_chunk", args.enc_chunk)
+    eng.set_option("last_q_cls", args.last_q_cls)
     eng.set_option("gemm", args.gemm)
     eng.set_option("attn", args.attn)
     eng.set_option("ln_fold", args.ln_fold)

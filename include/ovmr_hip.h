@@ -62,7 +62,7 @@ void ovmr_destroy(ovmr_handle* h);
 const char* ovmr_last_error(const ovmr_handle* h);
 const char* ovmr_version(void);
 
-/* Kernel-variant switch used by tests/bench to A/B implementations: key in {"gemm","attn","ln_fold","xval_fused","gelu_exact","fuse_im2col","enc_chunk"}.
+/* Kernel-variant switch used by tests/bench to A/B implementations: key in {"gemm","attn","ln_fold","xval_fused","gelu_exact","fuse_im2col","enc_chunk","last_q_cls"}.
  * "gemm" (default 8): 8 = 256-row LDS-DMA tiles with the ping-pong K loop (half-tile staging, counted waits), 6 = the same tiles with the double-buffered
  *   K loop, 0 = the 128x128 register-staged kernel everywhere (LayerNorm-folding and fused-argmax launches still take the tile kernel).
  * "attn" (default 3): 3 = single-pass persistent kernel where the shape is its own (non-causal, 192 < L <= 208), the 32x32x16 flash
@@ -78,7 +78,9 @@ const char* ovmr_version(void);
  *   linear output and rounds once -- closer to the real function, within a few fp16 steps of the reference's value, and 5 % off
  *   the c_fc launch.
  * "fuse_im2col" (default 1): conv1 on fp16 images with 16 x 16 patches -- the patch-embedding GEMM gathers its A rows from the image
- *   tensor inside its K loop; 0 writes the patch matrix out first (what fp32 images and other patch sizes always do).  Bit-identical. */
+ *   tensor inside its K loop; 0 writes the patch matrix out first (what fp32 images and other patch sizes always do).  Bit-identical.
+ * "last_q_cls" (default 1): the last vision block (whose output is read at the CLS row only, clip/model.py:423) projects K and V for every
+ *   token and Q for the CLS rows alone when a launch sequence holds at least 256 images; 0 projects Q for every token.  Bit-identical. */
 int ovmr_set_option(ovmr_handle* h, const char* key, int value);
 
 /* Weight ingestion -- replaces build_model()/convert_weights()/load_state_dict

@@ -52,6 +52,7 @@ struct GemmArgs {
     // (sum, sum of squares), one slot per 256-column tile of the producing GEMM, summed in slot order by the consumer
     // (deterministic: no atomics).
     const float* ln_stats; int ln_slots;   // EPI_LN_*: statistics of the A rows over K
+    int ln_stride;                         // ... slots between the statistics of consecutive A rows (0 = ln_slots: dense; the CLS-row launch strides over tokens)
     const float* ln_g; const float* ln_b;  // EPI_LN_*: [N] fp32 each
     float* stats_out;                      // EPI_BIAS_RES, optional: partial statistics of the stored C rows, [M][N/256][2]
     int nt_store;                          // v5: 0 = auto (streaming stores when C is much larger than the L2s), 1 = never, 2 = always

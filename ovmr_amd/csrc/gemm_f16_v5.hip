@@ -187,7 +187,7 @@ __global__ __launch_bounds__(512) void gemm_f16_v5_kernel(GemmArgs a, int tiles_
         col_c[BN5 + tid] = c1;
     } else if (LNF && tid - BN5 < BM) {
         const int r = tid - BN5;
-        const float2_t* sp = (const float2_t*)a.ln_stats + (long)min(m0 + r, a.M - 1) * a.ln_slots;
+        const float2_t* sp = (const float2_t*)a.ln_stats + (long)min(m0 + r, a.M - 1) * (a.ln_stride ? a.ln_stride : a.ln_slots);
         float su = 0.f, sq = 0.f;
         for (int sl = 0; sl < a.ln_slots; ++sl) { const float2_t p = sp[sl]; su += p[0]; sq += p[1]; }
         const float inv_k = 1.0f / (float)a.K;
@@ -338,7 +338,7 @@ __global__ __launch_bounds__(512) void gemm_f16_v5_kernel(GemmArgs a, int tiles_
         col_c[BN5 + tid] = c1;
     } else if (LNF && tid - BN5 < BM) {
         const int r = tid - BN5;
-        const float2_t* sp = (const float2_t*)a.ln_stats + (long)min(m0 + r, a.M - 1) * a.ln_slots;
+        const float2_t* sp = (const float2_t*)a.ln_stats + (long)min(m0 + r, a.M - 1) * (a.ln_stride ? a.ln_stride : a.ln_slots);
         float su = 0.f, sq = 0.f;
         for (int sl = 0; sl < a.ln_slots; ++sl) { const float2_t p = sp[sl]; su += p[0]; sq += p[1]; }
         const float inv_k = 1.0f / (float)a.K;

@@ -41,6 +41,7 @@ struct ovmr_handle {
     std::string err;
     bool finalized = false;
     int gelu_exact = 0;
+    int last_q_cls = 1;           // last vision block: Q projected for the CLS rows only (batches of >= 256 images)
     int fuse_im2col = 1;          // patch rows gathered by the patch-embedding GEMM itself (fp16 images, 16 x 16 patches)                       // 0: one-rounding fp32 QuickGELU in the c_fc epilogue (common.h quick_gelu_f32x2); 1: the reference's three fp16 rounding points
     int gemm_variant = 8, attn_variant = 3;   // defaults = fastest verified kernels (tools/gemm_bench.py, tools/attn_bench.py); attention 3 falls back to 1 / 0 by shape
     int ln_fold = 1;                          // fold ln_1 / ln_2 of the fp16 towers into the consuming GEMM where the shape allows
@@ -303,6 +304,7 @@ int ovmr_set_option(ovmr_handle* h, const char* key, int value) {
     if (!strcmp(key, "gemm")) h->gemm_variant = value;
     else if (!strcmp(key, "attn")) h->attn_variant = value;
     else if (!strcmp(key, "fuse_im2col")) h->fuse_im2col = value != 0;
+    else if (!strcmp(key, "last_q_cls")) h->last_q_cls = value != 0;
     else if (!strcmp(key, "enc_chunk")) {
         h->enc_chunk_forced = value > 0 ? value : 0;
         if (h->finalized)
@@ -516,11 +518,26 @@ int ovmr_encode_image(ovmr_handle* h, const void* image, int image_dtype, int B,
             const int H = W / 64;
             half_t* hid_c = hid;                       // [Bc, 4W]
             half_t* yc = y;                            // [Bc, W]
+            // ... and of the in-projection itself only K and V are needed for every token: with at least 256 images (a full row tile of
+            // CLS rows) the Q third runs as its own launch over the CLS rows (A and C strided by a sequence; bit-identical values),
+            // a third of this block's largest GEMM less
+            const bool q_cls_only = Bc >= 256 && h->last_q_cls;
+            const size_t WW = (size_t)W * W;
             if (stats) {
-                CK(launch_gemm_f16(gemm_ln(gemm(x, W, k.in_wf, W, qkv, 3 * W, M, 3 * W, W, EPI_LN_BIAS), stats, W / 256, k.in_g, k.in_bf), h->gemm_variant, s));
+                if (q_cls_only) {
+                    CK(launch_gemm_f16(gemm_ln(gemm(x, W, k.in_wf + WW, W, qkv + W, 3 * W, M, 2 * W, W, EPI_LN_BIAS), stats, W / 256, k.in_g + W, k.in_bf + W), h->gemm_variant, s));
+                    GemmArgs q = gemm_ln(gemm(x, L * W, k.in_wf, W, qkv, L * 3 * W, Bc, W, W, EPI_LN_BIAS), stats, W / 256, k.in_g, k.in_bf);
+                    q.ln_stride = L * (W / 256);
+                    CK(launch_gemm_f16(q, h->gemm_variant, s));
+                } else
+                    CK(launch_gemm_f16(gemm_ln(gemm(x, W, k.in_wf, W, qkv, 3 * W, M, 3 * W, W, EPI_LN_BIAS), stats, W / 256, k.in_g, k.in_bf), h->gemm_variant, s));
             } else {
                 CK(launch_layernorm(x, y, k.ln1_g, k.ln1_b, M, W, W, 0, s));
-                CK(launch_gemm_f16(gemm(y, W, k.in_w, W, qkv, 3 * W, M, 3 * W, W, EPI_BIAS, k.in_b), h->gemm_variant, s));
+                if (q_cls_only) {
+                    CK(launch_gemm_f16(gemm(y, W, (const half_t*)k.in_w + WW, W, qkv + W, 3 * W, M, 2 * W, W, EPI_BIAS, (const half_t*)k.in_b + W), h->gemm_variant, s));
+                    CK(launch_gemm_f16(gemm(y, L * W, k.in_w, W, qkv, L * 3 * W, Bc, W, W, EPI_BIAS, k.in_b), h->gemm_variant, s));
+                } else
+                    CK(launch_gemm_f16(gemm(y, W, k.in_w, W, qkv, 3 * W, M, 3 * W, W, EPI_BIAS, k.in_b), h->gemm_variant, s));
             }
             CK(launch_attention_f16_q(qkv, yc, Bc, L, 1, H, 0, h->attn_variant, s));
             CK(launch_gemm_f16(gemm(yc, W, k.out_w, W, rows, W, Bc, W, W, EPI_BIAS_RES, k.out_b, x, L * W), h->gemm_variant, s));
@@ -743,10 +760,10 @@ double ovmr_flops_per_image_executed(const ovmr_handle* h) {
     if (!h) return 0;
     const ovmr_model_desc& d = h->d;
     const double L = h->L, W = d.vision_width;
-    // last block as launched: K/V/Q projection of all tokens (6 L W^2), then one query row: scores + PV (4 L W), out_proj
-    // (2 W^2), MLP (16 W^2)
+    // last block as launched (batches of >= 256 images): K/V projection of all tokens (4 L W^2), Q of the CLS row (2 W^2), then one
+    // query row: scores + PV (4 L W), out_proj (2 W^2), MLP (16 W^2)
     const double last_full = 24.0 * L * W * W + 4.0 * L * L * W;
-    const double last_run = 6.0 * L * W * W + 4.0 * L * W + 18.0 * W * W;
+    const double last_run = 4.0 * L * W * W + 4.0 * L * W + 20.0 * W * W;
     return ovmr_flops_per_image(h) - last_full + last_run;
 }
 double ovmr_flops_per_prompt(const ovmr_handle* h, int seq_len) {

@@ -778,6 +778,29 @@ def test_xval_fused_argmax_equals_materialised_logits(C, R, D_name):
     assert int(out[1][1][C - 1]) == 0 or C - 1 == 1        # the duplicate of row 1 never wins a tie
 
 
+@pytest.mark.parametrize("name,n_img,fold", [("small", 300, 1), ("small", 256, 0), ("tiny", 257, 1), ("ViT-B/16", 256, 1)])
+def test_last_block_projects_q_for_the_cls_rows_only(name, n_img, fold):
+    """Only the CLS row of the last vision block reaches ln_post (clip/model.py:423): with at least 256 images the in-projection of that
+    block computes K and V for every token and Q for the CLS rows alone (A, C and the LayerNorm statistics strided by a sequence).  The
+    features are bit-equal to projecting Q for every token (option last_q_cls = 0), with the LayerNorm folded and not."""
+    from ovmr_amd import modules
+    spec = synth.SPECS[name]
+    sd = {k: torch.from_numpy(v) for k, v in synth.clip_state_dict(spec, SEED, jitter=True).items()}
+    e = modules.CLIPModel(sd, spec).engine(2)
+    e.load_state_dict({}, {k: torch.from_numpy(v) for k, v in synth.prompt_learner_state_dict(spec, 2, SEED, True).items()})
+    e._pl_loaded = True
+    e.finalize(n_img, 64, 256)
+    e.set_option("ln_fold", fold)
+    img = torch.from_numpy(synth.images(n_img, spec.image_resolution, seed=9)).half().cuda()
+    e.set_option("last_q_cls", 0)
+    want = e.encode_image(img, normalize=False).clone()
+    e.set_option("last_q_cls", 1)
+    got = e.encode_image(img, normalize=False).clone()
+    assert torch.equal(got, want) and bool(torch.isfinite(got.float()).all())
+    del e
+    torch.cuda.empty_cache()
+
+
 def test_encoder_chunk_is_whole_rounds_and_does_not_change_results():
     """ovmr_encode_chunk: the image tower encodes a batch in chunks chosen so that the 256-row-tile grids of the block GEMMs are whole
     rounds of the CUs (ViT-B/16 on the 256 CUs of an MI355X: 775 of a reserve of 775 or 1024, 665 of a reserve of 768); chunks that
