@@ -3,7 +3,8 @@
 and without the fused work our epilogues do (bias add, QuickGELU, residual) as separate torch ops."""
 import json, torch
 dev = "cuda"
-M = 512 * 197
+import sys
+M = (int(sys.argv[1]) if len(sys.argv) > 1 else 775) * 197     # images x tokens (bench.py: 775 images per launch sequence)
 def t(fn, reps=10):
     for _ in range(3): fn()
     torch.cuda.synchronize()
