@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Race screen for the hand-synchronised kernels (CDNA4 guide: "a sync-structure edit makes a NEW template: screen it for races
 over many runs at several sizes").  Every launch of a kernel on fixed inputs must reproduce the first launch bit for bit; the
-counted-vmcnt / staggered-barrier GEMM K loop (variant 8) and the persistent attention kernel with asm LDS-DMA (variant 3) are run
+counted-vmcnt / staggered-barrier GEMM K loop (variant 8, also gathering patch rows from an image tensor) and the attention kernels with
+asm LDS-DMA (variants 3 and 5) are run
 --reps times per shape, interleaved with a cache-thrashing copy so that DMA arrival times vary.
 
     python tools/race_screen.py [--reps 200]
@@ -44,8 +45,10 @@ for (M, N, K, epi) in ((4096, 1024, 768, 2), (5500, 768, 3072, 3), (2500, 2304, 
             mism += 1
     bad += mism
     print(f"gemm variant 8 {(M, N, K, epi)}: {reps} launches, {mism} differ from the first", flush=True)
-for variant in (3,):
-  for (B, L, H) in ((512, 197, 12), (37, 197, 12), (3, 208, 4), (300, 193, 12)):
+# (variant 5: the 32x32x16 flash kernel of the ViT-L lengths -- asm LDS-DMA into a two-stage ring, one barrier per key block, 3- and 4-wave workgroups)
+for variant, shapes in ((3, ((512, 197, 12), (37, 197, 12), (3, 208, 4), (300, 193, 12))),
+                        (5, ((64, 577, 16), (5, 577, 3), (96, 257, 16), (7, 300, 5), (9, 288, 1)))):
+  for (B, L, H) in shapes:
     g = torch.Generator(device="cuda").manual_seed(B + L)
     qkv = torch.randn((B * L, 3 * H * 64), generator=g, device="cuda").half()
     out, ref, mism = torch.empty((B * L, H * 64), dtype=torch.float16, device="cuda"), None, 0
@@ -60,6 +63,25 @@ for variant in (3,):
             mism += 1
     bad += mism
     print(f"attention variant {variant} {(B, L, H)}: {a.reps} launches, {mism} differ from the first", flush=True)
+# the whole image tower (patch rows gathered by the GEMM, LayerNorm folding, CLS-only last block) on a small model
+from ovmr_amd import modules, synth
+spec = synth.SPECS["small"]
+e = modules.CLIPModel({k: torch.from_numpy(v) for k, v in synth.clip_state_dict(spec, 11, jitter=True).items()}, spec).engine(2)
+e.load_state_dict({}, {k: torch.from_numpy(v) for k, v in synth.prompt_learner_state_dict(spec, 2, 11, True).items()})
+e._pl_loaded = True
+e.finalize(300, 64, 256)
+img = torch.from_numpy(synth.images(300, spec.image_resolution, seed=3)).half().cuda()
+ref, mism = None, 0
+for rep in range(a.reps):
+    if rep % 3 == 0:
+        junk.add_(1.0)
+    f = e.encode_image(img, normalize=False)
+    if ref is None:
+        ref = f.clone()
+    elif not torch.equal(f, ref):
+        mism += 1
+bad += mism
+print(f"image tower, small model, 300 images: {a.reps} encodes, {mism} differ from the first", flush=True)
 torch.cuda.synchronize()
 print("RACE SCREEN", "CLEAN" if bad == 0 else f"FAILED ({bad} differing launches)")
 sys.exit(1 if bad else 0)
