@@ -40,7 +40,7 @@ sys.path.insert(0, ROOT)
 # alone (query images / s: generation is set-up there), for the others the whole job as for the metric.
 PRESETS = {
     "metric": {"about": "ViT-B/16, 1000 classes x 16 shots + 4096 queries (the headline metric)", "set": {}},
-    "c2": {"about": "ViT-B/16, 100 classes x 8 shots generation + 1024 queries", "set": {"classes": 100, "shots": 8, "queries": 1024, "classes_per_batch": 96}},
+    "c2": {"about": "ViT-B/16, 100 classes x 8 shots generation + 1024 queries", "set": {"classes": 100, "shots": 8, "queries": 1024, "classes_per_batch": 100}},
     "c3": {"about": "ViT-B/16 fusion inference at batch 256 against 1000 x 16-shot classifiers; value = inference images/s",
            "set": {"queries": 16384}, "value": "inference"},
     "c5": {"about": "ViT-L/14@336px, 1000 classes x 32 shots + 512 queries (the MFMA-bound stress configuration)",
@@ -86,6 +86,16 @@ def parse():
     ap.add_argument("--force-dist", action="store_true",
                     help="N = 1 only: initialise a one-rank nccl (= RCCL) process group and take the sharded path, so that the packed "
                          "all-gather and the counter all-reduce run through librccl on this GPU")
+    ap.add_argument("--emulate-world", type=int, default=0,
+                    help="N > 1: a PROJECTION of the N-GPU job from this one GPU -- the whole job is timed as one rank, then every rank's shard of "
+                         "the N-rank job (its classes, its queries, the sharded code path with the two collectives served from the other ranks' "
+                         "recorded contributions) is timed ALONE on this GPU, no process group; projected_speedup = T(1 rank) / max_R T(rank R of N)")
+    ap.add_argument("--emulate-rank", type=int, default=-1, help="with --emulate-world: time this rank's shard only (-1: every rank)")
+    ap.add_argument("--stream-text", type=int, default=1,
+                    help="1: the zero-shot text rows of a loader batch's classes come out of the same text-tower pass as its multimodal and "
+                         "vision prompts (CustomCLIP(stream_text=True)); 0: one encode_text pass over all classes up front, as PromptLearner.__init__")
+    ap.add_argument("--dist-timeout", type=float, default=300.0,
+                    help="seconds a collective may take before the process group aborts this rank (it then exits non-zero; no retry)")
     ap.add_argument("--gelu-exact", type=int, default=int(os.environ.get("OVMR_GELU_EXACT", "0")),
                     help="1: QuickGELU with the reference's three fp16 rounding points; 0 (engine default): one rounding, fp32")
     ap.add_argument("--cpu-sample-classes", type=int, default=2, help="classes per CPU worker process and repetition (0: skip)")
@@ -124,13 +134,20 @@ def main():
     dev = torch.device(f"cuda:{local if backend == 'nccl' else local % max(1, torch.cuda.device_count())}")
     torch.cuda.set_device(dev)
     sharded = world > 1 or args.force_dist          # the class-sharded path with its two collectives
+    dist_info = None
     if sharded:
+        import datetime
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29512")
+        # a rank that fails or times out inside a collective is aborted by the process group's watchdog and exits non-zero: the
+        # launcher then ends the job -- no retry, no re-exec
+        os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "1")
+        to = datetime.timedelta(seconds=args.dist_timeout)
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
+            dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world, timeout=to)
         else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+            dist.init_process_group(backend, rank=rank, world_size=world, timeout=to)
+        dist_info = process_group_identity(dist, dev, backend, world)
 
     spec = synth.SPECS[args.model]
     C, S, Q, n_ctx = args.classes, args.shots, args.queries, 2
@@ -146,7 +163,8 @@ def main():
                            test_batch_size=args.batch)
     tok = torch.from_numpy(synth.class_token_ids(C, seed=4321))
     model = modules.CustomCLIP(cfg, tok, cm, prompt_learner_state=pl,
-                               reserve=(args.batch, max(256, min(C, 2048)), max(C, 1024)), distributed=sharded)
+                               reserve=(args.batch, max(256, min(C, 2048)), max(C, 1024)), distributed=sharded,
+                               stream_text=bool(args.stream_text))
     eng = model.engine
     eng.set_option("gelu_exact", args.gelu_exact)
     eng.set_option("fuse_im2col", args.fuse_im2col)
@@ -155,6 +173,11 @@ def main():
     eng.set_option("gemm", args.gemm)
     eng.set_option("attn", args.attn)
     eng.set_option("ln_fold", args.ln_fold)
+
+    if args.emulate_world > 1:
+        assert world == 1 and not sharded, "--emulate-world runs in ONE process without a process group"
+        print(json.dumps(emulate_world(args, model, spec, dev)), flush=True)
+        return
 
     # ---- this rank's shard of the job, resident in HBM (N(0,1) images, fp16), seed 1234 + rank
     c0, c1 = shard_range(C, rank, world)
@@ -171,7 +194,7 @@ def main():
         model._twin()                                   # set-up, like the first handle's: the second handle forward_batches uses (not part of a step)
 
     def generate():
-        if not sharded:
+        if not sharded and not args.stream_text:
             model.zero_shot_classifier = model.prompt_learner.zero_shot_classifier = \
                 model.prompt_learner.encode_zero_shot(model.tokenized_prompts)     # part of the job (:118-126)
         model.forward_prompt(loader)
@@ -246,7 +269,8 @@ def main():
                        "parallelism": f"class/query sharding over {world} rank(s); all-gather rows + all-reduce counters"
                                       + (f" (process group {dist.get_backend()}, sharded path forced)" if args.force_dist and world == 1 else ""),
                        "preset": args.preset, "gemm_variant": args.gemm, "attn_variant": args.attn, "ln_fold": args.ln_fold, "gelu_exact": args.gelu_exact,
-                       "encoder_reserve_images": args.batch, "encoder_chunk_images": eng.encode_chunk, "images_per_step": images_per_step},
+                       "stream_text": args.stream_text, "encoder_reserve_images": args.batch, "encoder_chunk_images": eng.encode_chunk, "images_per_step": images_per_step},
+            "dist": dist_info,
             "roofline": roof,
             "cpu_baseline": cpu,
             "phases": {"generation_images_per_s_rank0": round((c1 - c0) * S / tg, 1),
@@ -268,6 +292,182 @@ def main():
 
 
 # ------------------------------------------------------------------------------------------
+def device_identity(dev):
+    """A string that names the PHYSICAL device behind `dev`: its UUID where the runtime reports one, else its PCI address."""
+    import torch
+    p = torch.cuda.get_device_properties(dev)
+    uuid = getattr(p, "uuid", None)
+    if uuid is not None and str(uuid).strip("0-") != "":
+        return f"uuid:{uuid}"
+    pci = [getattr(p, k, None) for k in ("pci_domain_id", "pci_bus_id", "pci_device_id")]
+    if all(v is not None for v in pci):
+        return "pci:%04x:%02x:%02x" % tuple(int(v) for v in pci)
+    return f"index:{dev.index}"
+
+
+def process_group_identity(dist, dev, backend, world):
+    """What a SCALE record must prove about its process group: the collective library and its version, the rank count, and how
+    many DISTINCT devices the ranks sit on (all-gathered over the group itself).  With the RCCL backend every rank must own a
+    device of its own: anything else is a mis-launched job, not a scaling measurement -- every rank raises."""
+    import socket
+    import torch
+    ids = [None] * world
+    dist.all_gather_object(ids, f"{socket.gethostname()}/{device_identity(dev)}")
+    version = None
+    if backend == "nccl":
+        try:
+            v = torch.cuda.nccl.version()
+            version = ".".join(str(x) for x in v) if isinstance(v, (tuple, list)) else str(v)
+        except Exception:                                  # noqa: BLE001
+            version = "unknown"
+    info = {"backend": dist.get_backend(), "collective_library": "RCCL" if backend == "nccl" else backend, "rccl_version": version,
+            "ranks": dist.get_world_size(), "devices_seen": len(set(ids)), "device_ids": ids,
+            "hip_version": getattr(torch.version, "hip", None)}
+    if backend == "nccl" and info["devices_seen"] != world:
+        raise RuntimeError(f"{world} ranks over RCCL sit on {info['devices_seen']} distinct device(s): {ids}")
+    return info
+
+
+class EmulatedPeers:
+    """Stands where CustomCLIP keeps `torch.distributed` (modules.CustomCLIP._dist) for `--emulate-world`: rank `rank` of `world`
+    with NO process group.  The two collectives of the sharded path (ovmr_amd/shard.py) are served on the device from what the other
+    ranks would contribute -- their packed classifier blocks and their argmax counters, taken from a run of the whole job in this
+    process -- so the emulated rank executes the sharded code path on its own shard and ends with the whole job's bits."""
+
+    def __init__(self, rank, world):
+        self.rank, self.world = rank, world
+        self.peer_blocks = None          # [world * bound, K + 2] fp16: every rank's pack_block
+        self.peer_counts = None          # int32 [3, 2, C]: the other ranks' votes (None while recording)
+        self.local_counts = None
+
+    def get_rank(self):
+        return self.rank
+
+    def get_world_size(self):
+        return self.world
+
+    def get_backend(self):
+        return "emulated"
+
+    def all_gather_into_tensor(self, out, block):
+        bound = block.shape[0]
+        out.copy_(self.peer_blocks)
+        out[self.rank * bound:(self.rank + 1) * bound] = block
+
+    def all_reduce(self, c):
+        if self.peer_counts is None:
+            self.local_counts = c.clone()
+        else:
+            c += self.peer_counts
+
+
+def emulate_world(args, model, spec, dev):
+    """One JSON object: the whole job as one rank, then each rank's shard of the `--emulate-world` job alone on this GPU."""
+    import torch
+    from ovmr_amd.data import ResidentEvalSet
+    from ovmr_amd.shard import shard_range, pack_block, local_class_bound
+    N, C, S, Q, R = args.emulate_world, args.classes, args.shots, args.queries, spec.image_resolution
+    D, n_ctx = spec.embed_dim, 2
+    ov = None if args.overlap < 0 else bool(args.overlap)
+    # the data of every rank, drawn as the N-rank job draws it (seed 1234 + rank: exemplars, then queries)
+    ex, qs = [], []
+    for r in range(N):
+        ig = torch.Generator(device=dev).manual_seed(1234 + r)
+        c0, c1 = shard_range(C, r, N)
+        q0, q1 = shard_range(Q, r, N)
+        e = torch.empty(((c1 - c0) * S, 3, R, R), dtype=torch.float16, device=dev)
+        for s in range(0, e.shape[0], 1024):
+            e[s:s + 1024] = torch.randn((min(1024, e.shape[0] - s), 3, R, R), generator=ig, device=dev).half()
+        ex.append(e)
+        qs.append(torch.randn((q1 - q0, 3, R, R), generator=ig, device=dev).half())
+    ex_all, q_all = torch.cat(ex), torch.cat(qs)
+    del ex, qs
+    if args.overlap == 1 or (args.overlap < 0 and args.query_batch <= model.OVERLAP_MAX_BATCH):
+        model._twin()
+
+    def timed(step):
+        for _ in range(args.warmup):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / args.steps
+
+    def queries(q):
+        out = None
+        for out in model.forward_batches((q[b:b + args.query_batch] for b in range(0, q.shape[0], args.query_batch)),
+                                         stable_inputs=True, overlap=ov):
+            pass
+        return out
+
+    # ---- T(1 rank): the whole job, exactly bench.py's default step
+    full_loader = ResidentEvalSet(ex_all, torch.arange(C, device=dev), S, args.classes_per_batch, presharded=True)
+
+    def whole():
+        if not args.stream_text:
+            model.zero_shot_classifier = model.prompt_learner.zero_shot_classifier = \
+                model.prompt_learner.encode_zero_shot(model.tokenized_prompts)
+        model.forward_prompt(full_loader)
+        return queries(q_all)
+
+    t1 = timed(whole)
+    ref = {k: getattr(model, k).clone() for k in ("mm_classifier", "visual_classifer", "zero_shot_classifier", "fusion_weight", "visual_tokens")}
+    counts_full = model.xval_counts.clone()
+    ref_out_all = whole().clone()
+
+    # ---- every rank's shard, alone
+    bound = local_class_bound(C, N, True, max(1, args.batch // S))
+    blocks = []
+    for r in range(N):
+        c0, c1 = shard_range(C, r, N)
+        loc = torch.arange(c0, c1, device=dev)
+        blocks.append(pack_block(torch.cat([ref["mm_classifier"][loc], ref["visual_classifer"][loc], ref["zero_shot_classifier"][loc],
+                                            ref["visual_tokens"][loc].flatten(1)], dim=1), loc, bound))
+    peer_blocks = torch.cat(blocks)
+    ranks = range(N) if args.emulate_rank < 0 else [args.emulate_rank]
+    per_rank = []
+    for r in ranks:
+        c0, c1 = shard_range(C, r, N)
+        q0, q1 = shard_range(Q, r, N)
+        loader = ResidentEvalSet(ex_all[c0 * S:c1 * S], torch.arange(c0, c1, device=dev), S, args.classes_per_batch, presharded=True)
+        q = q_all[q0:q1]
+        emu = EmulatedPeers(r, N)
+        emu.peer_blocks = peer_blocks
+        model._dist, model._text_streamed = emu, True
+
+        def shard_step():
+            model.forward_prompt(loader)
+            return queries(q)
+
+        shard_step()                                        # records this rank's own votes
+        emu.peer_counts = counts_full - emu.local_counts
+        tr = timed(shard_step)
+        out = shard_step()
+        torch.cuda.synchronize()
+        tg = time.perf_counter(); model.forward_prompt(loader); torch.cuda.synchronize(); tg = time.perf_counter() - tg
+        same = all(torch.equal(getattr(model, k), ref[k]) for k in ref) and (out is None or torch.equal(out, ref_out_all[q0:q1]))
+        per_rank.append({"rank": r, "classes": c1 - c0, "exemplar_images": (c1 - c0) * S, "query_images": q1 - q0,
+                         "ms_per_step": round(1000 * tr, 3), "generation_ms": round(1000 * tg, 3),
+                         "images_per_s_alone": round(((c1 - c0) * S + q1 - q0) / tr, 1),
+                         "classifiers_fusion_weights_outputs_bit_equal_to_whole_job": bool(same)})
+    model._dist, model._text_streamed = None, bool(args.stream_text)
+    worst = max(p["ms_per_step"] for p in per_rank)
+    line = {"metric": f"PROJECTION of {N}-rank strong scaling from one MI355X: every rank's shard timed alone, no process group, no xGMI traffic",
+            "projection": True, "emulated_world": N, "ranks_timed": [p["rank"] for p in per_rank],
+            "whole_job_ms_one_rank": round(1000 * t1, 3), "whole_job_images_per_s": round((C * S + Q) / t1, 1),
+            "slowest_rank_ms": worst, "projected_speedup": round(1000 * t1 / worst, 3),
+            "projected_images_per_s": round((C * S + Q) / (worst / 1000), 1),
+            "not_included": "the RCCL all-gather of the packed rows and the all-reduce of the counters over xGMI (here: device copies of the "
+                            "recorded peer contributions), barrier skew between ranks, per-process set-up",
+            "collective_payload_bytes": {"all_gather_rows_per_rank": int(bound * (3 * D + n_ctx * D + 2) * 2), "all_reduce_counts": int(3 * 2 * C * 4)},
+            "steps": args.steps, "warmup": args.warmup, "per_rank": per_rank,
+            "config": {"workload": f"{args.model}, {C} classes x {S} shots + {Q} queries (batch {args.query_batch}), sharded over {N} emulated ranks",
+                       "preset": args.preset, "encoder_reserve_images": args.batch, "classes_per_batch": args.classes_per_batch}}
+    return line
+
+
 def device_clip_state(spec, gen, dev):
     import math
     import torch
@@ -335,16 +535,13 @@ def device_pl_state(spec, n_ctx, gen, dev):
     return sd
 
 
-def encoder_chunks(n_images, loader_batch, engine_batch, reserve=None):
-    """Image counts of the encoder launch sequences a stream of `n_images` produces: the loader hands over `loader_batch`
-    images at a time; what fits the engine's workspace (`reserve` images) is one launch sequence, a larger batch is encoded in
-    chunks of `engine_batch` (ovmr_encode_image / ovmr_encode_chunk)."""
+def encoder_chunks(eng, n_images, loader_batch):
+    """Image counts of the encoder launch sequences a stream of `n_images` produces -> {images: sequences}: the loader hands over
+    `loader_batch` images at a time, the engine plans each batch (Engine.encode_plan: one sequence if it fits the reserve, else chunks
+    of ovmr_encode_chunk images with a sub-round remainder folded into the last one)."""
     out = {}
     for s0 in range(0, n_images, loader_batch):
-        n = min(loader_batch, n_images - s0)
-        step = n if (reserve is not None and n <= reserve) else engine_batch
-        for c0 in range(0, n, step):
-            b = min(step, n - c0)
+        for b in eng.encode_plan(min(loader_batch, n_images - s0)):
             out[b] = out.get(b, 0) + 1
     return out
 
@@ -360,10 +557,8 @@ def measure_roofline(eng, spec, args, dev, n_exemplar_images, n_query_images):
     import torch
     lib = eng.lib
     N, K, L = 4 * spec.vision_width, spec.vision_width, spec.vision_tokens
-    chunk = eng.encode_chunk                            # images per launch sequence (<= --batch)
-    pinned = args.enc_chunk > 0
-    chunks = encoder_chunks(n_exemplar_images, args.classes_per_batch * args.shots, chunk, None if pinned else args.batch)
-    for b, n in encoder_chunks(n_query_images, args.query_batch, chunk, None if pinned else args.batch).items():
+    chunks = encoder_chunks(eng, n_exemplar_images, args.classes_per_batch * args.shots)
+    for b, n in encoder_chunks(eng, n_query_images, args.query_batch).items():
         chunks[b] = chunks.get(b, 0) + n
     layers = spec.vision_layers - 1                                   # the last block runs the CLS row only (other kernels)
     g = torch.Generator(device=dev).manual_seed(7)

@@ -63,11 +63,12 @@ const char* ovmr_last_error(const ovmr_handle* h);
 const char* ovmr_version(void);
 
 /* Kernel-variant switch used by tests/bench to A/B implementations: key in {"gemm","attn","ln_fold","xval_fused","gelu_exact","fuse_im2col","enc_chunk","last_q_cls"}.
- * "gemm" (default 8): 8 = 256-row LDS-DMA tiles with the ping-pong K loop (half-tile staging, counted waits), 6 = the same tiles with the double-buffered
- *   K loop, 0 = the 128x128 register-staged kernel everywhere (LayerNorm-folding and fused-argmax launches still take the tile kernel).
+ * "gemm" (default 8): 8 = 256-row LDS-DMA tiles with the ping-pong K loop (half-tile staging, counted waits) and, for latency-bound shapes
+ *   (at most one round -- 256 -- of 64 x 64 tiles: the text tower on a few dozen prompts, CLS-row chains), the 64 x 64 kernel that splits K
+ *   over its waves; 7 = 8 without that kernel (A/B); 6 = the 256-row tiles with the double-buffered K loop; 9 = the 64 x 64 split-K kernel wherever it takes the shape (tests);
+ *   0 = the 128x128 register-staged kernel everywhere (LayerNorm-folding and fused-argmax launches still take the tile kernel).
  * "attn" (default 3): 3 = single-pass persistent kernel where the shape is its own (non-causal, 192 < L <= 208), the 32x32x16 flash
  *   kernel (= 5) for non-causal L >= 256 (ViT-L), else as 1; 5 = that kernel where it applies, else as 1;
- *   4 = the same arithmetic with free-running producer / consumer waves (LDS flags instead of the workgroup barrier), same shapes;
  *   1 = flash-style LDS-DMA kernel for L >= 128, else as 0; 0 = the plain flash-style kernel.
  * "ln_fold" (default 1): ln_1 / ln_2 of the fp16 towers are folded into the consuming GEMM where the shape allows
  *   (width % 256 == 0 and >= 256 token rows); 0 runs the separate LayerNorm kernel everywhere.
@@ -103,6 +104,11 @@ int ovmr_finalize(ovmr_handle* h, int max_images, int max_prompts, int max_class
 int ovmr_encode_image(ovmr_handle* h, const void* image, int image_dtype, int B,
                       void* out_f16, int normalize, ovmr_stream stream);
 
+/* The launch sequences ovmr_encode_image splits a batch of B images into (diagnostics / bench accounting; no reference
+ * counterpart: the reference encodes a loader batch in one piece, trainers/mm_classifier_one_prompt.py:243-245): writes up to
+ * max_sizes image counts into sizes, returns the number of sequences (-1 before ovmr_finalize). */
+int ovmr_encode_plan(const ovmr_handle* h, int B, int* sizes, int max_sizes);
+
 /* TextEncoder.forward (trainers/mm_classifier_one_prompt.py:80-91).  prompts: [N, context_length,
  * transformer_width] fp16 (already embedded); index: [N] int32 row that is projected (EOS for mm
  * prompts, 1+n_ctx for vision prompts, :163-165); seq_len: number of leading positions that must
@@ -116,6 +122,23 @@ int ovmr_encode_text_embedded(ovmr_handle* h, const void* prompts_f16, const int
  * ids.argmax(-1).  normalize as above (the zero-shot text classifier uses 1, :118-126). */
 int ovmr_encode_text_ids(ovmr_handle* h, const int64_t* ids, int N, int seq_len,
                          void* out_f16, int normalize, ovmr_stream stream);
+
+/* Several prompt families through the text transformer in ONE pass.  The reference encodes the multimodal prompts, the vision
+ * prompts (get_mm_v_feats, trainers/mm_classifier_one_prompt.py:200-212) and the zero-shot text prompts (:118-126) as three
+ * separate TextEncoder / encode_text calls; the arithmetic of a sequence does not depend on its neighbours, so here the token
+ * rows of all groups share the GEMM launches of every block and only attention, the read-out gather and the projection run per
+ * group (each group keeps its own seq_len: truncation to the last needed row is exact under the causal mask, clip/model.py:802-809).
+ * A group is EITHER embedded prompts + read-out rows (as ovmr_encode_text_embedded) OR token ids (as ovmr_encode_text_ids).
+ * Rows that do not fit the workspace fall back to one pass per group.  Results equal the per-group entry points up to the
+ * kernel choice the larger row count implies (1 - cos ~ 1e-6). */
+typedef struct {
+    const void* prompts_f16;   /* [n, context_length, transformer_width] fp16, or NULL when ids is given */
+    const int64_t* ids;        /* [n, context_length] int64, or NULL */
+    const int32_t* index;      /* [n] read-out rows (embedded prompts only) */
+    int n, seq_len, normalize; /* as the single-group entry points */
+    void* out_f16;             /* [n, embed_dim] fp16 */
+} ovmr_text_group;
+int ovmr_encode_text_groups(ovmr_handle* h, const ovmr_text_group* groups, int n_groups, ovmr_stream stream);
 
 /* token_embedding(ids).type(fp16) (trainers/mm_classifier_one_prompt.py:129-130): ids [N, L] int64
  * -> out [N, L, transformer_width] fp16. */

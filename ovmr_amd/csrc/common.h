@@ -152,6 +152,7 @@ __device__ __forceinline__ float wave_max(float v) {
 
 // ---- launchers (one per .hip translation unit) -------------------------------------------
 int launch_gemm_f16(const GemmArgs& a, int variant, hipStream_t s);
+bool gemm_f16_is_small(int M, int N);   // latency-bound shape: variant 8 runs it on the 64 x 64 split-K kernel (gemm_f16_small.hip)
 int launch_gemm_f32(const GemmArgs& a, hipStream_t s);
 int launch_layernorm(const void* x, void* y, const float* g, const float* b, int rows, int D,
                      long in_row_stride, int is_f32, hipStream_t s);

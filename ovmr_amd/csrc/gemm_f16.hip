@@ -129,10 +129,20 @@ int launch_t128(const GemmArgs& a, hipStream_t s) {
 }  // namespace
 
 int launch_gemm_f16_v5(const GemmArgs& a, int variant, hipStream_t s);  // gemm_f16_v5.hip: 256(128)x256x64 LDS-DMA tiles, fused epilogues
+int launch_gemm_f16_small(const GemmArgs& a, hipStream_t s);            // gemm_f16_small.hip: 64x64 tiles, K split over the waves (latency-bound shapes)
+
+// Shapes that are at most ONE round of 64 x 64 tiles on the 256 CUs: there the K loop of a tile kernel runs at one memory latency
+// per K-tile on a mostly idle machine and the split-K kernel (gemm_f16_small.hip) wins -- 8-9 us against 10-14 us at K = 512,
+// 20 against 28 at K = 2048, 27 against 43 at K = 3072, 3-5x at a few dozen rows; beyond one round its missing operand reuse costs
+// more than the latency it hides (profiles/r04d_small_gemm_bench.log: the rule matches the faster kernel on all 81 measured shapes
+// but the two within 5 %).
+bool gemm_f16_is_small(int M, int N) { return (long)((M + 63) / 64) * ((N + 63) / 64) <= 256; }
 
 // variant 0: the 128x128 register-staged kernel above for every shape; 6: 256-row tiles with the double-buffered K loop;
-// 8 (default): 6 with the ping-pong K loop.  6 / 8 fall back to the 128x128 kernel for shapes they do not take
-// (M < 256, N < 128, ...).  Experiment builds (OVMR_EXPERIMENTS) add timing-only ablation variants (gemm_f16_v5.hip).
+// 8 (default): 6 with the ping-pong K loop, and the 64x64 split-K kernel (gemm_f16_small.hip) for latency-bound shapes
+// (gemm_f16_is_small); 7: 8 without that kernel (A/B); 9: the 64x64 split-K kernel wherever it takes the shape (tests).  6 / 8 / 9 fall back to the 128x128
+// kernel for shapes they do not take (M < 256, N < 128, K not a multiple of 128 ...).  Experiment builds (OVMR_EXPERIMENTS) add
+// timing-only ablation variants (gemm_f16_v5.hip).
 int launch_gemm_f16(const GemmArgs& a_in, int variant, hipStream_t s) {
     GemmArgs a = a_in;
     if (variant >= 100) {                   // variant = kernel + 100 * QuickGELU form (common.h quick_gelu_fast_h4)
@@ -141,7 +151,7 @@ int launch_gemm_f16(const GemmArgs& a_in, int variant, hipStream_t s) {
     }
     if (a.M <= 0 || a.N <= 0) return 0;
     if (a.K <= 0 || (a.K % BK) != 0 || (a.lda & 7) || (a.ldw & 7)) return -2;  // caller pads K to 64
-    const int v5 = variant == 0 ? 8 : variant;
+    const int v5 = (variant == 0 || variant == 9 || variant == 7) ? 8 : variant;
     if (a.im2col_R) {                                                           // only the v5 kernel gathers patch rows from the image; -4: shape not supported
         const int rc = launch_gemm_f16_v5(a, v5, s);
         return rc == -100 ? -4 : rc;
@@ -153,6 +163,12 @@ int launch_gemm_f16(const GemmArgs& a_in, int variant, hipStream_t s) {
     if (a.epi == EPI_LN_BIAS || a.epi == EPI_LN_BIAS_QGELU || a.stats_out) {   // only the v5 kernel folds LayerNorm
         const int rc = launch_gemm_f16_v5(a, v5, s);
         return rc == -100 ? -4 : rc;
+    }
+    if (variant == 7) variant = 8;          // A/B: variant 8 without the split-K kernel (the caller's LayerNorm-fold rule keys on 8 as well)
+    else if (variant == 9 || (variant == 8 && gemm_f16_is_small(a.M, a.N))) {
+        const int rc = launch_gemm_f16_small(a, s);
+        if (rc != -100) return rc;
+        if (variant == 9) variant = 8;
     }
     if (variant >= 1) {
         const int rc = launch_gemm_f16_v5(a, variant, s);

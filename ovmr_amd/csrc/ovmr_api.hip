@@ -62,6 +62,8 @@ struct ovmr_handle {
     int enc_chunk_forced = 0;     // option "enc_chunk": > 0 pins the chunk, 0 = pick_encode_chunk
     int n_cu = 0;
     int enc_chunk = 0;            // images per launch sequence of ovmr_encode_image (<= max_images; pick_encode_chunk); option "enc_chunk" overrides
+    int enc_fold = 0;             // a remainder of at most this many images (one round of the narrowest GEMM grid) joins the last full sequence
+    int img_cap = 0;              // images the workspace holds: max_images + enc_fold
     long agg_rows_cap = 0, logit_elems_cap = 0;
 };
 
@@ -176,8 +178,10 @@ size_t agg_ws_bytes(const ovmr_handle* h, long rows) {
 }
 
 // LayerNorm folding applies when the v5 GEMM takes the shape (it then also emits the statistics): see common.h.
+// Not for latency-bound passes (gemm_f16_is_small: the N = W launches -- out_proj, c_proj -- then take the 64 x 64 split-K kernel,
+// which emits no statistics; the separate LayerNorm kernel costs ~4 us there).
 bool can_fold_ln(const ovmr_handle* h, const Block& k, int M, int W) {
-    return h->ln_fold && k.in_wf && M >= 256 && (W % 256) == 0 && W / 256 <= 64;
+    return h->ln_fold && k.in_wf && M >= 256 && (W % 256) == 0 && W / 256 <= 64 && !(h->gemm_variant == 8 && gemm_f16_is_small(M, W));
 }
 
 GemmArgs gemm_ln(GemmArgs a, const float* stats, int slots, const float* g, const float* b) {
@@ -192,16 +196,27 @@ GemmArgs gemm_stats(GemmArgs a, float* stats) {
 // One pre-LN residual attention block (clip/model.py:191-194) on fp16 activations.
 // stats != nullptr: ln_1 / ln_2 are folded into in_proj / c_fc.  On entry `stats` holds the partial row statistics of x
 // (launch_row_stats, or the previous block's c_proj epilogue); on exit those of the new x.
+// `groups` (text tower, ovmr_encode_text_groups): the token rows are several groups of sequences with their own length each --
+// the GEMMs run over all rows at once, attention once per group; nullptr: nseq sequences of L tokens.
+struct SeqGroup { int nseq, L; long row0; };
+
 int run_block_f16(ovmr_handle* h, const Block& k, half_t* x, half_t* y, half_t* qkv, half_t* hid,
-                  int nseq, int L, int W, int causal, hipStream_t s, float* stats = nullptr) {
-    const int M = nseq * L, H = W / 64, slots = W / 256;
+                  int nseq, int L, int W, int causal, hipStream_t s, float* stats = nullptr,
+                  const std::vector<SeqGroup>* groups = nullptr) {
+    int M = nseq * L;
+    if (groups) { M = 0; for (auto& g : *groups) M += g.nseq * g.L; }
+    const int H = W / 64, slots = W / 256;
     if (stats) {
         CK(launch_gemm_f16(gemm_ln(gemm(x, W, k.in_wf, W, qkv, 3 * W, M, 3 * W, W, EPI_LN_BIAS), stats, slots, k.in_g, k.in_bf), h->gemm_variant, s));
     } else {
         CK(launch_layernorm(x, y, k.ln1_g, k.ln1_b, M, W, W, 0, s));
         CK(launch_gemm_f16(gemm(y, W, k.in_w, W, qkv, 3 * W, M, 3 * W, W, EPI_BIAS, k.in_b), h->gemm_variant, s));
     }
-    CK(launch_attention_f16(qkv, y, nseq, L, H, causal, h->attn_variant, s));
+    if (groups) {
+        for (auto& g : *groups)
+            CK(launch_attention_f16(qkv + g.row0 * 3 * W, y + g.row0 * W, g.nseq, g.L, H, causal, h->attn_variant, s));
+    } else
+        CK(launch_attention_f16(qkv, y, nseq, L, H, causal, h->attn_variant, s));
     CK(launch_gemm_f16(gemm_stats(gemm(y, W, k.out_w, W, x, W, M, W, W, EPI_BIAS_RES, k.out_b, x, W), stats), h->gemm_variant, s));
     if (stats) {
         CK(launch_gemm_f16(gemm_ln(gemm(x, W, k.fc_wf, W, hid, 4 * W, M, 4 * W, W, EPI_LN_BIAS_QGELU), stats, slots, k.fc_g, k.fc_bf), h->gemm_variant + (h->gelu_exact ? 0 : 100), s));
@@ -232,17 +247,84 @@ int normalize_rows(ovmr_handle* h, half_t* x, int rows, int D, int mode, hipStre
     return 0;
 }
 
-// Text tower after the embedding: blocks, gather, ln_final, projection (clip/model.py:824-831).
-int run_text_tower(ovmr_handle* h, half_t* x, half_t* y, half_t* qkv, half_t* hid, half_t* rows, const int* index,
-                   int N, int Ls, half_t* out, int normalize, hipStream_t s, float* stats_buf) {
-    const int W = h->d.transformer_width;
-    float* stats = !h->txt.empty() && can_fold_ln(h, h->txt[0], N * Ls, W) ? stats_buf : nullptr;
-    if (stats) CK(launch_row_stats(x, stats, N * Ls, W, W / 256, s));
-    for (auto& k : h->txt) CK(run_block_f16(h, k, x, y, qkv, hid, N, Ls, W, 1, s, stats));
-    CK(launch_gather_rows_f16(x, index, rows, N, Ls, W, s));
-    CK(launch_layernorm(rows, rows, h->ln_final_g, h->ln_final_b, N, W, W, 0, s));
-    CK(launch_gemm_f16(gemm(rows, W, h->textproj_t, W, out, h->d.embed_dim, N, h->d.embed_dim, W, EPI_NONE), h->gemm_variant, s));
-    return normalize_rows(h, out, N, h->d.embed_dim, normalize, s);
+// One group of prompts of a text-tower pass: N sequences truncated to Ls tokens, read-out row `index` per sequence.
+struct TextGroup {
+    const half_t* prompts = nullptr;   // [N, context_length, W] embedded prompts, or
+    const int64_t* ids = nullptr;      // [N, context_length] token ids (read-out row = argmax, clip/model.py:831)
+    const int* index = nullptr;        // embedded prompts: [N]
+    int N = 0, Ls = 0, normalize = 0;
+    half_t* out = nullptr;             // [N, embed_dim]
+};
+
+size_t text_groups_ws_bytes(const ovmr_handle* h, size_t M, size_t N) {
+    const size_t W = h->d.transformer_width;
+    return align_up(M * W * 2) * 2 + align_up(M * 3 * W * 2) + align_up(M * 4 * W * 2) + align_up(N * W * 2) + align_up(N * 4) +
+           align_up(M * ((W + 255) / 256) * 8);
+}
+
+// Text tower (clip/model.py:824-831) over all groups in ONE pass: embedding per group, the blocks' GEMMs over all token rows,
+// causal attention per group (each with its own length -- truncation to the last needed row is exact under the causal mask),
+// read-out row gather, ln_final and projection per group.  The caller has checked that the rows fit the workspace.
+int run_text_groups(ovmr_handle* h, const std::vector<TextGroup>& gs, hipStream_t s) {
+    const ovmr_model_desc& d = h->d;
+    const int W = d.transformer_width, Lc = d.context_length, E = d.embed_dim;
+    size_t M = 0, N = 0;
+    std::vector<SeqGroup> seq;
+    for (auto& g : gs) { seq.push_back({g.N, g.Ls, (long)M}); M += (size_t)g.N * g.Ls; N += g.N; }
+    Carver c(h->ws);
+    half_t* x = c.take<half_t>(M * W);
+    half_t* y = c.take<half_t>(M * W);
+    half_t* qkv = c.take<half_t>(M * 3 * W);
+    half_t* hid = c.take<half_t>(M * 4 * W);
+    half_t* rows = c.take<half_t>(N * W);
+    int* index = c.take<int>(N);
+    float* stats_buf = c.take<float>(M * ((W + 255) / 256) * 2);
+    size_t n0 = 0;
+    for (size_t i = 0; i < gs.size(); ++i) {
+        const TextGroup& g = gs[i];
+        half_t* xg = x + seq[i].row0 * W;
+        if (g.ids) CK(launch_text_embed_ids(g.ids, Lc, h->tok_emb, h->pos16_txt, xg, index + n0, g.N, Lc, g.Ls, W, s));
+        else CK(launch_text_add_pos(g.prompts, Lc, h->pos16_txt, xg, g.N, g.Ls, W, s));
+        n0 += g.N;
+    }
+    float* stats = !h->txt.empty() && can_fold_ln(h, h->txt[0], (int)M, W) ? stats_buf : nullptr;
+    if (stats) CK(launch_row_stats(x, stats, (int)M, W, W / 256, s));
+    for (auto& k : h->txt) CK(run_block_f16(h, k, x, y, qkv, hid, 0, 0, W, 1, s, stats, &seq));
+    n0 = 0;
+    for (size_t i = 0; i < gs.size(); ++i) {
+        const TextGroup& g = gs[i];
+        CK(launch_gather_rows_f16(x + seq[i].row0 * W, g.ids ? index + n0 : g.index, rows + n0 * W, g.N, g.Ls, W, s));
+        n0 += g.N;
+    }
+    CK(launch_layernorm(rows, rows, h->ln_final_g, h->ln_final_b, (int)N, W, W, 0, s));
+    n0 = 0;
+    for (auto& g : gs) {
+        CK(launch_gemm_f16(gemm(rows + n0 * W, W, h->textproj_t, W, g.out, E, g.N, E, W, EPI_NONE), h->gemm_variant, s));
+        CK(normalize_rows(h, g.out, g.N, E, g.normalize, s));
+        n0 += g.N;
+    }
+    return 0;
+}
+
+// One group, any size: chunks of max_prompts sequences.
+int run_text_group_chunked(ovmr_handle* h, const TextGroup& g, hipStream_t s) {
+    const int Lc = h->d.context_length, W = h->d.transformer_width, E = h->d.embed_dim;
+    for (int n0 = 0; n0 < g.N; n0 += h->max_prompts) {
+        TextGroup c = g;
+        c.N = std::min(h->max_prompts, g.N - n0);
+        if (g.ids) c.ids = g.ids + (size_t)n0 * Lc;
+        else { c.prompts = g.prompts + (size_t)n0 * Lc * W; c.index = g.index + n0; }
+        c.out = g.out + (size_t)n0 * E;
+        CK(run_text_groups(h, {c}, s));
+    }
+    return 0;
+}
+
+int check_text_call(ovmr_handle* h, int seq_len, int normalize) {
+    if (normalize < 0 || normalize > 2) return OVMR_E_ARG;
+    if (!h->finalized) return fail(h, OVMR_E_STATE, "ovmr_finalize() has not been called");
+    if (seq_len < 1 || seq_len > h->d.context_length) return fail(h, OVMR_E_ARG, "seq_len %d outside [1,%d]", seq_len, h->d.context_length);
+    return 0;
 }
 
 }  // namespace
@@ -297,6 +379,23 @@ static int pick_encode_chunk(int max_images, int L, int W, int n_cu) {
         if (r > best_rate * 1.002) { best_rate = r; best = b; }      // (a smaller chunk has to buy more than launch overheads cost)
     }
     return best;
+}
+
+// Launch sequences of a batch of B images: one if it fits the reserve; else chunks of enc_chunk images, a remainder of at most
+// enc_fold images (less than one round of tiles on the narrowest grid: as its own sequence it would pay a whole round on every launch
+// PLUS ~70 launches of latency, 2.1 ms for 25 ViT-B/16 images where the extra round inside the previous sequence costs 1.8) folded
+// into the last full chunk.
+static std::vector<int> encode_plan(const ovmr_handle* h, int B) {
+    std::vector<int> plan;
+    const int chunk = h->enc_chunk_forced > 0 ? h->enc_chunk : (B > h->max_images && h->enc_chunk > 0 ? h->enc_chunk : h->max_images);
+    for (int b0 = 0; b0 < B;) {
+        int Bc = std::min(chunk, B - b0);
+        const int left = B - b0 - Bc;
+        if (left > 0 && left <= h->enc_fold && Bc + left <= h->img_cap) Bc += left;
+        plan.push_back(Bc);
+        b0 += Bc;
+    }
+    return plan;
 }
 
 int ovmr_set_option(ovmr_handle* h, const char* key, int value) {
@@ -452,9 +551,16 @@ int ovmr_finalize(ovmr_handle* h, int max_images, int max_prompts, int max_class
         HIP_CHECK_RET(hipDeviceGetAttribute(&h->n_cu, hipDeviceAttributeMultiprocessorCount, dev));
         h->enc_chunk = h->enc_chunk_forced > 0 ? std::min(h->enc_chunk_forced, max_images) : pick_encode_chunk(max_images, h->L, (int)d.vision_width, h->n_cu);
     }
+    {
+        // fold slack: one round of the narrowest grid (N = W: W/256 column tiles of 256 rows), for reserves of two rounds or more
+        const long nw = std::max<long>(1, (long)W / 256), round_images = (long)h->n_cu * 256 / (nw * h->L);
+        const bool big = ((long)max_images * h->L + 255) / 256 * nw >= 2L * h->n_cu;
+        h->enc_fold = big ? (int)std::min<long>(round_images, max_images / 4) : 0;
+        h->img_cap = max_images + h->enc_fold;
+    }
     h->agg_rows_cap = (long)max_classes * (d.n_ctx + 32);
     h->logit_elems_cap = 32L << 20;
-    size_t need = image_ws_bytes(h, max_images);
+    size_t need = image_ws_bytes(h, h->img_cap);
     need = std::max(need, text_ws_bytes(h, max_prompts));
     need = std::max(need, agg_ws_bytes(h, h->agg_rows_cap));
     need = std::max(need, align_up((size_t)h->logit_elems_cap * 2) * 3 + align_up((size_t)65536 * E * 2));
@@ -479,10 +585,9 @@ int ovmr_encode_image(ovmr_handle* h, const void* image, int image_dtype, int B,
     const int W = d.vision_width, R = d.image_resolution, L = h->L, G2 = h->G * h->G, E = d.embed_dim;
     const size_t px = (size_t)3 * R * R * (image_dtype == OVMR_F32 ? 4 : 2);
     // a batch that fits the workspace is ONE launch sequence; a larger one is split into chunks of enc_chunk images (pick_encode_chunk),
-    // unless the option pins the chunk
-    const int chunk = h->enc_chunk_forced > 0 ? h->enc_chunk : (B > h->max_images && h->enc_chunk > 0 ? h->enc_chunk : h->max_images);
-    for (int b0 = 0; b0 < B; b0 += chunk) {
-        const int Bc = std::min(chunk, B - b0);
+    // unless the option pins the chunk; a sub-round remainder joins the last chunk (encode_plan)
+    int b0 = 0;
+    for (const int Bc : encode_plan(h, B)) {
         const int M = Bc * L;
         Carver c(h->ws);
         half_t* col = c.take<half_t>((size_t)Bc * G2 * h->Kpad);
@@ -534,8 +639,12 @@ int ovmr_encode_image(ovmr_handle* h, const void* image, int image_dtype, int B,
             } else {
                 CK(launch_layernorm(x, y, k.ln1_g, k.ln1_b, M, W, W, 0, s));
                 if (q_cls_only) {
-                    CK(launch_gemm_f16(gemm(y, W, (const half_t*)k.in_w + WW, W, qkv + W, 3 * W, M, 2 * W, W, EPI_BIAS, (const half_t*)k.in_b + W), h->gemm_variant, s));
-                    CK(launch_gemm_f16(gemm(y, L * W, k.in_w, W, qkv, L * 3 * W, Bc, W, W, EPI_BIAS, k.in_b), h->gemm_variant, s));
+                    // (both launches take the kernel the all-token launch of last_q_cls = 0 would take -- the split-K kernel, 9, if
+                    //  [M, 3W] is a latency-bound shape, else the tile kernels, 7 -- so that the K summation order, and with it every
+                    //  bit, is the same either way)
+                    const int v = h->gemm_variant != 8 ? h->gemm_variant : (gemm_f16_is_small(M, 3 * W) ? 9 : 7);
+                    CK(launch_gemm_f16(gemm(y, W, (const half_t*)k.in_w + WW, W, qkv + W, 3 * W, M, 2 * W, W, EPI_BIAS, (const half_t*)k.in_b + W), v, s));
+                    CK(launch_gemm_f16(gemm(y, L * W, k.in_w, W, qkv, L * 3 * W, Bc, W, W, EPI_BIAS, k.in_b), v, s));
                 } else
                     CK(launch_gemm_f16(gemm(y, W, k.in_w, W, qkv, 3 * W, M, 3 * W, W, EPI_BIAS, k.in_b), h->gemm_variant, s));
             }
@@ -549,58 +658,57 @@ int ovmr_encode_image(ovmr_handle* h, const void* image, int image_dtype, int B,
         CK(launch_layernorm(rows, rows, h->ln_post_g, h->ln_post_b, Bc, W, W, 0, s));
         CK(launch_gemm_f16(gemm(rows, W, h->proj_t, W, out, E, Bc, E, W, EPI_NONE), h->gemm_variant, s));
         CK(normalize_rows(h, out, Bc, E, normalize ? 1 : 0, s));
+        b0 += Bc;
     }
     return 0;
+}
+
+int ovmr_encode_plan(const ovmr_handle* h, int B, int* sizes, int max_sizes) {
+    if (!h || !h->finalized || B < 0) return -1;
+    const std::vector<int> plan = encode_plan(h, B);
+    for (size_t i = 0; i < plan.size() && (int)i < max_sizes; ++i) sizes[i] = plan[i];
+    return (int)plan.size();
 }
 
 int ovmr_encode_text_embedded(ovmr_handle* h, const void* prompts_f16, const int32_t* index, int N, int seq_len,
                               void* out_f16, int normalize, ovmr_stream stream) {
     if (h && N == 0) return 0;
-    if (!h || !prompts_f16 || !index || !out_f16 || N < 0 || normalize < 0 || normalize > 2) return OVMR_E_ARG;
-    if (!h->finalized) return fail(h, OVMR_E_STATE, "ovmr_finalize() has not been called");
-    const ovmr_model_desc& d = h->d;
-    if (seq_len < 1 || seq_len > d.context_length) return fail(h, OVMR_E_ARG, "seq_len %d outside [1,%d]", seq_len, d.context_length);
-    hipStream_t s = (hipStream_t)stream;
-    const int W = d.transformer_width, Lc = d.context_length, E = d.embed_dim;
-    for (int n0 = 0; n0 < N; n0 += h->max_prompts) {
-        const int Nc = std::min(h->max_prompts, N - n0);
-        const size_t M = (size_t)Nc * seq_len;
-        Carver c(h->ws);
-        half_t* x = c.take<half_t>(M * W);
-        half_t* y = c.take<half_t>(M * W);
-        half_t* qkv = c.take<half_t>(M * 3 * W);
-        half_t* hid = c.take<half_t>(M * 4 * W);
-        half_t* rows = c.take<half_t>((size_t)Nc * W);
-        float* stats_buf = c.take<float>(M * ((W + 255) / 256) * 2);
-        CK(launch_text_add_pos((const half_t*)prompts_f16 + (size_t)n0 * Lc * W, Lc, h->pos16_txt, x, Nc, seq_len, W, s));
-        CK(run_text_tower(h, x, y, qkv, hid, rows, index + n0, Nc, seq_len, (half_t*)out_f16 + (size_t)n0 * E, normalize, s, stats_buf));
-    }
-    return 0;
+    if (!h || !prompts_f16 || !index || !out_f16 || N < 0) return OVMR_E_ARG;
+    if (int rc = check_text_call(h, seq_len, normalize)) return rc;
+    TextGroup g;
+    g.prompts = (const half_t*)prompts_f16; g.index = index; g.N = N; g.Ls = seq_len; g.normalize = normalize; g.out = (half_t*)out_f16;
+    return run_text_group_chunked(h, g, (hipStream_t)stream);
 }
 
 int ovmr_encode_text_ids(ovmr_handle* h, const int64_t* ids, int N, int seq_len, void* out_f16, int normalize,
                          ovmr_stream stream) {
     if (h && N == 0) return 0;
-    if (!h || !ids || !out_f16 || N < 0 || normalize < 0 || normalize > 2) return OVMR_E_ARG;
-    if (!h->finalized) return fail(h, OVMR_E_STATE, "ovmr_finalize() has not been called");
-    const ovmr_model_desc& d = h->d;
-    if (seq_len < 1 || seq_len > d.context_length) return fail(h, OVMR_E_ARG, "seq_len %d outside [1,%d]", seq_len, d.context_length);
-    hipStream_t s = (hipStream_t)stream;
-    const int W = d.transformer_width, Lc = d.context_length, E = d.embed_dim;
-    for (int n0 = 0; n0 < N; n0 += h->max_prompts) {
-        const int Nc = std::min(h->max_prompts, N - n0);
-        const size_t M = (size_t)Nc * seq_len;
-        Carver c(h->ws);
-        half_t* x = c.take<half_t>(M * W);
-        half_t* y = c.take<half_t>(M * W);
-        half_t* qkv = c.take<half_t>(M * 3 * W);
-        half_t* hid = c.take<half_t>(M * 4 * W);
-        half_t* rows = c.take<half_t>((size_t)Nc * W);
-        int* index = c.take<int>((size_t)Nc);
-        float* stats_buf = c.take<float>(M * ((W + 255) / 256) * 2);
-        CK(launch_text_embed_ids(ids + (size_t)n0 * Lc, Lc, h->tok_emb, h->pos16_txt, x, index, Nc, Lc, seq_len, W, s));
-        CK(run_text_tower(h, x, y, qkv, hid, rows, index, Nc, seq_len, (half_t*)out_f16 + (size_t)n0 * E, normalize, s, stats_buf));
+    if (!h || !ids || !out_f16 || N < 0) return OVMR_E_ARG;
+    if (int rc = check_text_call(h, seq_len, normalize)) return rc;
+    TextGroup g;
+    g.ids = ids; g.N = N; g.Ls = seq_len; g.normalize = normalize; g.out = (half_t*)out_f16;
+    return run_text_group_chunked(h, g, (hipStream_t)stream);
+}
+
+int ovmr_encode_text_groups(ovmr_handle* h, const ovmr_text_group* groups, int n_groups, ovmr_stream stream) {
+    if (!h || (!groups && n_groups > 0) || n_groups < 0) return OVMR_E_ARG;
+    std::vector<TextGroup> gs;
+    size_t M = 0, N = 0;
+    for (int i = 0; i < n_groups; ++i) {
+        const ovmr_text_group& u = groups[i];
+        if (u.n == 0) continue;
+        if (u.n < 0 || !u.out_f16 || (!u.ids && (!u.prompts_f16 || !u.index)) || (u.ids && u.prompts_f16)) return OVMR_E_ARG;
+        if (int rc = check_text_call(h, u.seq_len, u.normalize)) return rc;
+        TextGroup g;
+        g.prompts = (const half_t*)u.prompts_f16; g.ids = u.ids; g.index = u.index; g.N = u.n; g.Ls = u.seq_len;
+        g.normalize = u.normalize; g.out = (half_t*)u.out_f16;
+        gs.push_back(g);
+        M += (size_t)u.n * u.seq_len; N += u.n;
     }
+    if (gs.empty()) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    if (text_groups_ws_bytes(h, M, N) <= h->ws_bytes) return run_text_groups(h, gs, s);      // one pass over all groups
+    for (auto& g : gs) CK(run_text_group_chunked(h, g, s));                                    // too many rows for the workspace
     return 0;
 }
 

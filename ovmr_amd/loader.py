@@ -25,15 +25,17 @@ PIXEL_MEAN = (0.48145466, 0.4578275, 0.40821073)      # configs/trainers/MM_CLS_
 PIXEL_STD = (0.26862954, 0.26130258, 0.27577711)
 
 
-def preprocess_u8(u8: torch.Tensor, out: torch.Tensor = None, stream=None) -> torch.Tensor:
-    """uint8 [B, R, R, 3] on the device -> normalised fp16 [B, 3, R, R] (ovmr_preprocess_u8)."""
+def preprocess_u8(u8: torch.Tensor, out: torch.Tensor = None, stream=None, mean=PIXEL_MEAN, std=PIXEL_STD) -> torch.Tensor:
+    """uint8 [B, R, R, 3] on the device -> normalised fp16 [B, 3, R, R] (ovmr_preprocess_u8).  mean=None: ToTensor only (no Normalize)."""
+    if mean is None:
+        mean, std = (0.0, 0.0, 0.0), (1.0, 1.0, 1.0)
     from . import runtime
     lib = runtime.load_library()
     assert u8.is_cuda and u8.dtype == torch.uint8 and u8.dim() == 4 and u8.shape[3] == 3 and u8.is_contiguous()
     B, R = int(u8.shape[0]), int(u8.shape[1])
     if out is None:
         out = torch.empty((B, 3, R, R), dtype=torch.float16, device=u8.device)
-    mean, std = (ctypes.c_float * 3)(*PIXEL_MEAN), (ctypes.c_float * 3)(*PIXEL_STD)
+    mean, std = (ctypes.c_float * 3)(*mean), (ctypes.c_float * 3)(*std)
     s = stream if stream is not None else torch.cuda.current_stream(u8.device)
     rc = lib.ovmr_preprocess_u8(ctypes.c_void_p(u8.data_ptr()), B, R, mean, std, ctypes.c_void_p(out.data_ptr()),
                                 ctypes.c_void_p(s.cuda_stream))
@@ -46,13 +48,17 @@ class PipelinedFolderLoader:
     """Iterable of {"img", "label"} dict batches over (path, label) items; see the module docstring.
 
     With world > 1 the loader is class-sharded like cli.FolderLoader (`presharded = True`).  `stats` after an iteration:
-    images, batches, wall_s, decode_wait_s (the caller blocked on the workers), consumer_gpu_s (device time between a batch
-    becoming available and the caller asking for the next one: the encoder's share), encoder_idle_fraction = 1 - consumer_gpu_s / wall_s."""
+    images, batches, wall_s, decode_wait_s (the caller blocked on the workers), decode_bound_fraction = decode_wait_s / wall_s (the
+    share of the job the host spent waiting for JPEG decode: robust whatever streams the consumer uses), consumer_gpu_s (device time
+    on the caller's CURRENT stream between a batch becoming available and the caller asking for the next one) and
+    encoder_idle_fraction = 1 - consumer_gpu_s / wall_s -- an UPPER bound when the consumer runs the encoder on side streams
+    (CustomCLIP.forward_batches: only the staging copy and the hand-over wait fall on the current stream)."""
 
     def __init__(self, items: Sequence[Tuple[str, int]], batch_size: int, size: int, rank: int = 0, world: int = 1,
                  num_classes: int = 0, workers: int = 8, prefetch: int = 3, device: str = "cuda:0", chunk: int = 8,
-                 fast_decode: bool = False):
+                 fast_decode: bool = False, interpolation: str = "bicubic", mean=PIXEL_MEAN, std=PIXEL_STD):
         self.bs, self.size = int(batch_size), int(size)
+        self.interpolation, self.mean, self.std = interpolation, mean, std
         self.presharded = world > 1
         if world > 1:
             from .shard import shard_range
@@ -82,7 +88,7 @@ class PipelinedFolderLoader:
         staging = None if pinned else torch.empty((B, R, R, 3), dtype=torch.uint8).pin_memory()
         ctx = mp.get_context("spawn")               # this process has initialised the GPU: never fork it
         task_q, done_q = ctx.Queue(), ctx.Queue()
-        procs = [ctx.Process(target=_decode_worker.worker_main, args=(shm.name, slots, B, R, self.fast, task_q, done_q), daemon=True)
+        procs = [ctx.Process(target=_decode_worker.worker_main, args=(shm.name, slots, B, R, self.fast, task_q, done_q, self.interpolation), daemon=True)
                  for _ in range(self.workers)]
         for p in procs:
             p.start()
@@ -117,7 +123,16 @@ class PipelinedFolderLoader:
                     side.wait_event(consumed[k])
                 tw = time.perf_counter()
                 while pending[slot] > 0:
-                    s, n, err = done_q.get(timeout=600)
+                    try:
+                        s, n, err = done_q.get(timeout=2)
+                    except Exception:                             # queue.Empty: is anyone still decoding?
+                        dead = [p for p in procs if not p.is_alive()]
+                        if dead:
+                            raise RuntimeError(f"{len(dead)} decode worker(s) died (exit codes {[p.exitcode for p in dead]}) -- killed by the "
+                                               "kernel for memory, or a crash inside the image library") from None
+                        if time.perf_counter() - tw > 600:
+                            raise RuntimeError("decode workers made no progress for 600 s") from None
+                        continue
                     if err:
                         raise RuntimeError(f"decode worker failed: {err}")
                     pending[s] -= n
@@ -131,7 +146,7 @@ class PipelinedFolderLoader:
                         dev_u8[k][:n].copy_(staging[:n], non_blocking=True)
                     copied[slot] = torch.cuda.Event()
                     copied[slot].record(side)
-                    preprocess_u8(dev_u8[k][:n], dev_f16[k][:n], stream=side)
+                    preprocess_u8(dev_u8[k][:n], dev_f16[k][:n], stream=side, mean=self.mean, std=self.std)
                     ready = torch.cuda.Event()
                     ready.record(side)
                 if not pinned:
@@ -169,5 +184,6 @@ class PipelinedFolderLoader:
             shm.unlink()
             wall = time.perf_counter() - t0
             self.stats = {"images": len(self.items), "batches": nb, "workers": self.workers, "wall_s": wall, "decode_wait_s": t_wait,
+                          "decode_bound_fraction": t_wait / wall if wall > 0 else 0.0,
                           "consumer_gpu_s": gpu_ms / 1e3, "images_per_s": len(self.items) / wall if wall > 0 else 0.0,
                           "encoder_idle_fraction": max(0.0, 1.0 - gpu_ms / 1e3 / wall) if wall > 0 else 0.0, "pinned_ring": bool(pinned)}

@@ -268,10 +268,14 @@ class CustomCLIP:
     """trainers/mm_classifier_one_prompt.py:179-364 (evaluation / classifier-generation branch)."""
 
     def __init__(self, cfg, classnames, clip_model: CLIPModel, tokenizer=None,
-                 prompt_learner_state: Optional[Dict] = None, reserve=None, distributed: Optional[bool] = None):
+                 prompt_learner_state: Optional[Dict] = None, reserve=None, distributed: Optional[bool] = None,
+                 stream_text: bool = False):
         """distributed: None = shard over the default process group when it has more than one rank; True = take the sharded
         path whenever a process group is initialised (also with ONE rank: the collectives then run through the backend --
-        RCCL for "nccl" -- on this rank's own rows, tests/test_hip_distributed.py); False = never."""
+        RCCL for "nccl" -- on this rank's own rows, tests/test_hip_distributed.py); False = never.
+        stream_text: the zero-shot text rows (:118-126) are not encoded up front by PromptLearner.__init__ but batch by batch inside
+        forward_prompt, in the same text-tower pass as the batch's multimodal and vision prompts (what sharded ranks and
+        vocabularies of >= 5000 classes always do); same rows, two tower passes fewer per loader batch."""
         self.cfg = cfg
         import torch.distributed as dist
         ready = dist.is_available() and dist.is_initialized()
@@ -283,7 +287,8 @@ class CustomCLIP:
         if reserve is None:
             reserve = (cfg.DATALOADER.TEST.BATCH_SIZE if hasattr(cfg.DATALOADER, "TEST") else 256, 256, 1024)
         self.prompt_learner = PromptLearner(cfg, classnames, clip_model, tokenizer, prompt_learner_state,
-                                            compute_zero_shot=self._dist is None, reserve=reserve)
+                                            compute_zero_shot=self._dist is None and not stream_text, reserve=reserve)
+        self._text_streamed = bool(stream_text) or self._dist is not None
         self.engine = self.prompt_learner.engine
         self.tokenized_prompts = self.prompt_learner.tokenized_prompts
         self.image_encoder = _ImageEncoder(self.engine)
@@ -304,16 +309,19 @@ class CustomCLIP:
         return self
 
     # :200-212
-    def get_mm_v_feats(self, mm_prompts, mm_lens, v_prompts, v_lens):
+    def get_mm_v_feats(self, mm_prompts, mm_lens, v_prompts, v_lens, text_ids=None):
+        """The reference runs the text encoder once on the multimodal prompts and once on the vision prompts (:202-203); here both
+        prompt families -- and, with `text_ids` [Cb, 77], the zero-shot text prompts of the same classes (:118-126) -- share ONE pass
+        of the tower (Engine.encode_text_groups: each family keeps its own truncated length).  Returns (mm, v) or (mm, v, text)."""
         pl = self.prompt_learner
         n_ctx = pl.n_ctx
-        mm_list, v_list = [], []
-        for mm_prompt, v_prompt in zip(mm_prompts, v_prompts):
-            # normalize=2: x/x.norm() (:204), mean over the single list element, F.normalize (:210)
-            mm_list.append(self.engine.encode_text_embedded(mm_prompt, mm_lens, pl.max_eos + n_ctx + 1, normalize=2))
-            v_list.append(self.engine.encode_text_embedded(v_prompt, v_lens, 2 + n_ctx, normalize=2))
-        assert len(mm_list) == 1
-        return mm_list[0], v_list[0]
+        assert len(mm_prompts) == 1 and len(v_prompts) == 1
+        # normalize=2: x/x.norm() (:204), mean over the single list element, F.normalize (:210)
+        groups = [dict(prompts=mm_prompts[0], index=mm_lens, seq_len=pl.max_eos + n_ctx + 1, normalize=2),
+                  dict(prompts=v_prompts[0], index=v_lens, seq_len=2 + n_ctx, normalize=2)]
+        if text_ids is not None:
+            groups.append(dict(ids=text_ids, seq_len=pl.max_eos + 1, normalize=1))
+        return tuple(self.engine.encode_text_groups(groups))
 
     @staticmethod
     def _batch_images(batch, device):
@@ -359,13 +367,15 @@ class CustomCLIP:
             feats = e.encode_image(image, normalize=True).reshape(num_cls, S, -1)   # :243-245
             self.eval_feat4cls[exemplar_label] = feats                              # :247
             mm_p, mm_l, v_p, v_l, tokens = pl(feats, exemplar_label, pl.eos_index[exemplar_label])   # :248
-            mm, v = self.get_mm_v_feats(mm_p, mm_l, v_p, v_l)                       # :249
+            if streamed_text:                                                       # :249 + the batch's own zero-shot rows (:118-126), one tower pass
+                mm, v, t = self.get_mm_v_feats(mm_p, mm_l, v_p, v_l, self.tokenized_prompts[exemplar_label])
+                text_clf[exemplar_label] = t
+            else:
+                mm, v = self.get_mm_v_feats(mm_p, mm_l, v_p, v_l)                   # :249
             self.mm_classifier[exemplar_label] = mm                                 # :251
             self.visual_classifer[exemplar_label] = v                               # :252
             self.inference_text_initialized[exemplar_label] = 1                     # :254
             self.visual_tokens[exemplar_label] = tokens.half()                      # :255
-            if streamed_text:
-                text_clf[exemplar_label] = pl.encode_zero_shot(self.tokenized_prompts[exemplar_label])
             local_labels.append(exemplar_label)
         local = torch.cat(local_labels) if local_labels else torch.zeros(0, dtype=torch.long, device=dev)
 
@@ -387,10 +397,11 @@ class CustomCLIP:
             self.inference_text_initialized = (seen[:C] == 1).to(torch.int32)       # every class from exactly one rank
         if streamed_text:
             self.zero_shot_classifier = self.prompt_learner.zero_shot_classifier = text_clf
-        assert bool(self.inference_text_initialized.bool().all()), "a class received no exemplar batch"   # :259
-
+        all_initialized = self.inference_text_initialized.bool().all()              # :259 -- read back below, behind the enqueued head:
+                                                                                    # a host round trip here would idle the GPU in front of it
         self.fusion_weight = self._xval_fusion_weight(local, self.mm_classifier, self.visual_classifer,
                                                       self.zero_shot_classifier, float(self.cfg.EVAL_TAU))   # :261-274
+        assert bool(all_initialized), "a class received no exemplar batch"          # :259
         if rank == 0 and self.cfg.OUTPUT_DIR:
             os.makedirs(self.cfg.OUTPUT_DIR, exist_ok=True)
             torch.save({"text_classifier": self.zero_shot_classifier.float(),      # :276-285, all fp32

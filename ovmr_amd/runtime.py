@@ -31,6 +31,11 @@ class ModelDesc(ctypes.Structure):
                                    "transformer_layers", "n_ctx", "agg_layers")]
 
 
+class TextGroup(ctypes.Structure):
+    """ovmr_text_group (include/ovmr_hip.h)."""
+    _fields_ = [("prompts_f16", c_p), ("ids", c_p), ("index", c_p), ("n", c_i), ("seq_len", c_i), ("normalize", c_i), ("out_f16", c_p)]
+
+
 # name -> (restype, argtypes); mirrors include/ovmr_hip.h one to one
 SIGNATURES = {
     "ovmr_create": (c_i, [ctypes.POINTER(ModelDesc), ctypes.POINTER(c_p)]),
@@ -43,6 +48,7 @@ SIGNATURES = {
     "ovmr_encode_image": (c_i, [c_p, c_p, c_i, c_i, c_p, c_i, c_p]),
     "ovmr_encode_text_embedded": (c_i, [c_p, c_p, c_p, c_i, c_i, c_p, c_i, c_p]),
     "ovmr_encode_text_ids": (c_i, [c_p, c_p, c_i, c_i, c_p, c_i, c_p]),
+    "ovmr_encode_text_groups": (c_i, [c_p, ctypes.POINTER(TextGroup), c_i, c_p]),
     "ovmr_embed_tokens": (c_i, [c_p, c_p, c_i, c_i, c_p, c_p]),
     "ovmr_generate_tokens": (c_i, [c_p, c_p, c_i, c_i, c_p, c_p]),
     "ovmr_assemble_prompts": (c_i, [c_p, c_p, c_p, c_p, c_i, c_p, c_p]),
@@ -53,6 +59,7 @@ SIGNATURES = {
     "ovmr_logit_scale": (ctypes.c_float, [c_p]),
     "ovmr_preprocess_u8": (c_i, [c_p, c_i, c_i, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float), c_p, c_p]),
     "ovmr_encode_chunk": (ctypes.c_int, [c_p]),
+    "ovmr_encode_plan": (c_i, [c_p, c_i, ctypes.POINTER(c_i), c_i]),
     "ovmr_flops_per_image": (ctypes.c_double, [c_p]),
     "ovmr_flops_per_image_executed": (ctypes.c_double, [c_p]),
     "ovmr_flops_per_prompt": (ctypes.c_double, [c_p, c_i]),
@@ -185,6 +192,14 @@ class Engine:
         """Images per launch sequence of encode_image (chosen by ovmr_finalize so that the GEMM grids are whole rounds of the CUs)."""
         return int(self.lib.ovmr_encode_chunk(self.h))
 
+    def encode_plan(self, B: int) -> list:
+        """Image counts of the launch sequences encode_image runs a batch of B images as."""
+        buf = (c_i * 4096)()
+        n = int(self.lib.ovmr_encode_plan(self.h, int(B), buf, 4096))
+        if n < 0:
+            raise OvmrError("ovmr_encode_plan: the engine is not finalized")
+        return [int(buf[i]) for i in range(min(n, 4096))]
+
     def flops_per_image(self) -> float:
         return float(self.lib.ovmr_flops_per_image(self.h))
 
@@ -232,6 +247,28 @@ class Engine:
         self._ck(self.lib.ovmr_encode_text_ids(self.h, _ptr(ids), N, sl, _ptr(out), int(normalize), _stream()),
                  "ovmr_encode_text_ids")
         return out
+
+    def encode_text_groups(self, groups) -> list:
+        """Several prompt families in ONE pass of the text tower (ovmr_encode_text_groups).  Each group is a dict with either
+        `prompts` [N, context_length, W] + `index` [N] or `ids` [N, context_length], and `seq_len`, `normalize` as the
+        single-group calls.  Returns one [N, embed_dim] fp16 tensor per group."""
+        arr = (TextGroup * len(groups))()
+        keep, outs = [], []
+        for a, g in zip(arr, groups):
+            sl = int(g.get("seq_len") or self.spec.context_length)
+            if g.get("ids") is not None:
+                ids = self._dev(g["ids"], torch.int64)
+                keep.append(ids)
+                a.prompts_f16, a.ids, a.index, n = None, ids.data_ptr(), None, ids.shape[0]
+            else:
+                pr, ix = self._dev(g["prompts"], torch.float16), self._dev(g["index"], torch.int32)
+                keep += [pr, ix]
+                a.prompts_f16, a.ids, a.index, n = pr.data_ptr(), None, ix.data_ptr(), pr.shape[0]
+            out = torch.empty((n, self.spec.embed_dim), dtype=torch.float16, device=self.device)
+            a.n, a.seq_len, a.normalize, a.out_f16 = n, sl, int(g.get("normalize", 0)), out.data_ptr()
+            outs.append(out)
+        self._ck(self.lib.ovmr_encode_text_groups(self.h, arr, len(groups), _stream()), "ovmr_encode_text_groups")
+        return outs
 
     def embed_tokens(self, ids: torch.Tensor) -> torch.Tensor:
         ids = self._dev(ids, torch.int64)

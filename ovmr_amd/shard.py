@@ -46,23 +46,29 @@ def _staged(t: torch.Tensor, dist) -> torch.Tensor:
     return t.cpu() if dist.get_backend() == "gloo" and t.is_cuda else t
 
 
-def all_gather_rows(rows: torch.Tensor, labels: torch.Tensor, bound: int, dist) -> Tuple[torch.Tensor, torch.Tensor]:
-    """ONE all-gather of a ragged set of fp16 rows.  rows [n_local, K] fp16, labels [n_local] (class ids), n_local <= bound
-    (`local_class_bound`, identical on every rank).  Every rank contributes a [bound, K + 2] block: its rows, the int32
-    label of each row carried in two extra fp16 columns (bit pattern, not value), padding rows labelled -1.
-    Returns (all_rows [world * bound, K], all_labels [world * bound] int32 with -1 on padding rows), rank-major."""
+def pack_block(rows: torch.Tensor, labels: torch.Tensor, bound: int) -> torch.Tensor:
+    """One rank's contribution to the all-gather: [bound, K + 2] fp16 = its rows, the int32 label of each row carried in two
+    extra fp16 columns (bit pattern, not value), padding rows labelled -1."""
     n, K = rows.shape
     if n > bound:
         raise RuntimeError(f"this rank produced {n} classes, more than the bound {bound} every rank agreed on: the eval-set "
                            "loader yields more than TEST.BATCH_SIZE // NUM_SHOTS classes per batch")
     assert rows.dtype == torch.float16
-    world = dist.get_world_size()
     lab = torch.full((bound,), -1, dtype=torch.int32, device=rows.device)
     lab[:n] = labels.to(torch.int32)
     block = torch.zeros((bound, K + 2), dtype=torch.float16, device=rows.device)
     block[:n, :K] = rows
     block[:, K:] = lab.view(torch.float16).reshape(bound, 2)
-    block = _staged(block, dist)
+    return block
+
+
+def all_gather_rows(rows: torch.Tensor, labels: torch.Tensor, bound: int, dist) -> Tuple[torch.Tensor, torch.Tensor]:
+    """ONE all-gather of a ragged set of fp16 rows.  rows [n_local, K] fp16, labels [n_local] (class ids), n_local <= bound
+    (`local_class_bound`, identical on every rank).  Every rank contributes one `pack_block`.
+    Returns (all_rows [world * bound, K], all_labels [world * bound] int32 with -1 on padding rows), rank-major."""
+    K = rows.shape[1]
+    world = dist.get_world_size()
+    block = _staged(pack_block(rows, labels, bound), dist)
     out = torch.empty((world * bound, K + 2), dtype=torch.float16, device=block.device)
     dist.all_gather_into_tensor(out, block)
     out = out.to(rows.device)

@@ -60,3 +60,25 @@ def test_rccl_collectives_with_one_rank_bit_equal(tmp_path):
         for k in ("mm", "v", "t", "tokens", "counts", "w", "out"):
             assert torch.equal(single[k], got[k]), f"nccl world 1, presharded {presharded}: {k} differs"
         assert got["files"] == ["mm_classifiers.pt", "visual_tokens.pt"]
+
+
+@pytest.mark.timeout(900)
+def test_bench_line_proves_its_process_group(tmp_path):
+    """A SCALE record must say what it ran on: `bench.py --force-dist` (one rank, process group nccl = RCCL on cuda:0, the sharded
+    path) carries `dist` = {backend, rccl_version, ranks, devices_seen, device_ids}, devices_seen equal to the rank count (bench.py
+    raises on every rank otherwise); without a process group the field is null.  Small job: 12 classes x 4 shots + 32 queries."""
+    import json
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    base = [sys.executable, os.path.join(repo, "bench.py"), "--classes", "12", "--shots", "4", "--queries", "32", "--query-batch", "16",
+            "--steps", "1", "--warmup", "1", "--no-cpu-baseline"]
+    lines = {}
+    for tag, extra in (("dist", ["--force-dist", "--dist-timeout", "120"]), ("plain", [])):
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        r = subprocess.run(base + extra, env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+        lines[tag] = json.loads([l for l in r.stdout.splitlines() if l.startswith('{"metric')][-1])
+    d = lines["dist"]["dist"]
+    assert lines["plain"]["dist"] is None
+    assert d["backend"] == "nccl" and d["collective_library"] == "RCCL" and d["ranks"] == 1 and d["devices_seen"] == 1
+    assert len(d["device_ids"]) == 1 and d["rccl_version"] and d["rccl_version"][0].isdigit()
+    assert lines["dist"]["n_gpus"] == 1 and lines["dist"]["value"] > 0

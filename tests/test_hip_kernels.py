@@ -10,7 +10,8 @@ import torch
 pytestmark = pytest.mark.gpu
 
 EPI_NONE, EPI_BIAS, EPI_BIAS_QGELU, EPI_BIAS_RES, EPI_PATCH, EPI_SCALE = range(6)
-GEMM_VARIANTS = [0, 6, 8]       # 0: 128x128 register-staged; 6 / 8: 256-row LDS-DMA tiles (double-buffered / ping-pong K loop)
+GEMM_VARIANTS = [0, 6, 8, 9]    # 0: 128x128 register-staged; 6 / 8: 256-row LDS-DMA tiles (double-buffered / ping-pong K loop; 8 also picks
+                                # the 64x64 split-K kernel for latency-bound shapes); 9: the 64x64 split-K kernel wherever it takes the shape
 ATTN_VARIANTS = [0, 1, 3, 5]     # 5: 32x32x16 flash kernel for L >= 256 (variant 3 routes ViT-L there); variant 4 lives in the experiment build only
 
 
@@ -63,7 +64,7 @@ def _ref_gemm_f16(A, W, bias, res, pos, epi, scale, rows_in, rows_out):
     (4 * 196, 768, 768, EPI_PATCH), (300, 768, 3072, EPI_BIAS_RES), (1, 512, 768, EPI_NONE),
     (2048, 512, 2048, EPI_BIAS_RES), (513, 1536, 512, EPI_BIAS),
 ])
-def test_gemm_f16(lib, variant, M, N, K, epi):
+def test_gemm_f16(lib, variant, M, N, K, epi, with_stats=True):
     g = torch.Generator().manual_seed(M * 7 + N * 3 + K + epi)
     A = (torch.randn(M, K, generator=g) * 0.5).half()
     W = (torch.randn(N, K, generator=g) * K ** -0.5).half()
@@ -77,11 +78,19 @@ def test_gemm_f16(lib, variant, M, N, K, epi):
     d = "cuda"
     Ad, Wd, bd, pd = A.to(d), W.to(d), bias.to(d), pos.to(d)
     C = res.clone().to(d) if epi == EPI_BIAS_RES else torch.zeros(out_rows, N, dtype=torch.float16, device=d)
-    rc = lib.ovmr_debug_gemm(0, variant, _p(Ad), _p(Wd), _p(bd), _p(C) if epi == EPI_BIAS_RES else None, _p(pd), _p(C),
-                             M, N, K, N, epi, scale, rows_in, rows_out, _s())
+    # (with EPI_BIAS_RES the hook reads `pos` as the statistics output of the LayerNorm fold: only the tile kernels emit it)
+    extra = pd if epi == EPI_PATCH else None
+    if epi == EPI_BIAS_RES and with_stats and N % 256 == 0:
+        extra = torch.zeros((M, N // 256, 2), dtype=torch.float32, device=d)      # [M][N/256][2] partial (sum, sum of squares) of the stored rows
+    rc = lib.ovmr_debug_gemm(0, variant, _p(Ad), _p(Wd), _p(bd), _p(C) if epi == EPI_BIAS_RES else None,
+                             _p(extra), _p(C), M, N, K, N, epi, scale, rows_in, rows_out, _s())
     assert rc == 0
     torch.cuda.synchronize()
     got = C.float().cpu()
+    if epi == EPI_BIAS_RES and extra is not None and M >= 256:                     # the statistics epilogue of the tile kernels
+        st = extra.sum(dim=1).cpu().double()
+        np.testing.assert_allclose(st[:, 0].numpy(), got.double().sum(-1).numpy(), rtol=1e-4, atol=1e-2)
+        np.testing.assert_allclose(st[:, 1].numpy(), (got.double() ** 2).sum(-1).numpy(), rtol=1e-4, atol=1e-2)
     if epi == EPI_PATCH:
         keep = torch.ones(out_rows, dtype=torch.bool)
         keep[::rows_out] = False        # CLS rows are written by a separate kernel
@@ -91,6 +100,36 @@ def test_gemm_f16(lib, variant, M, N, K, epi):
     assert torch.isfinite(got).all()
     assert float((got - ref).abs().max()) <= tol, f"max err {(got - ref).abs().max()}"
     assert float(((got - ref).abs() > tol / 8).float().mean()) < 0.02
+
+
+@pytest.mark.parametrize("M,N,K,epi", [
+    (40, 512, 2048, EPI_BIAS_RES), (3250, 512, 2048, EPI_BIAS_RES), (3250, 512, 512, EPI_BIAS_RES), (1500, 1536, 512, EPI_BIAS),
+    (1500, 2048, 512, EPI_BIAS_QGELU), (775, 768, 3072, EPI_BIAS_RES), (775, 3072, 768, EPI_BIAS_QGELU), (125, 512, 512, EPI_NONE),
+    (100, 1000, 512, EPI_SCALE), (64, 64, 128, EPI_NONE), (65, 130, 384, EPI_BIAS), (63, 72, 640, EPI_BIAS_RES), (2000, 100, 512, EPI_SCALE),
+])
+def test_gemm_f16_split_k_small(lib, M, N, K, epi):
+    """The 64 x 64 kernel that splits K over its four waves (gemm_f16_small.hip; variant 9 forces it, the default variant 8 picks it
+    for these latency-bound shapes): every prefetch depth (K / 128 = 1, 3, 4, 5, 6, 16, 24 steps per wave), ragged M / N edges, the
+    in-place residual epilogue, against the fp64 statement."""
+    test_gemm_f16(lib, 9, M, N, K, epi, with_stats=False)
+    test_gemm_f16(lib, 8, M, N, K, epi, with_stats=False)
+
+
+def test_gemm_f16_split_k_small_is_deterministic_and_row_independent(lib):
+    """The partial tiles are summed in wave order, not by arrival: repeated launches are bit-equal, and a row's values do not depend
+    on the rows around it (the same rows as part of a larger M)."""
+    g = torch.Generator().manual_seed(5)
+    M, N, K = 777, 512, 2048
+    A = (torch.randn(M, K, generator=g) * 0.5).half().cuda()
+    W = (torch.randn(N, K, generator=g) * K ** -0.5).half().cuda()
+    b = (torch.randn(N, generator=g) * 0.1).half().cuda()
+    outs = []
+    for m in (M, M, 300):
+        C = torch.zeros(m, N, dtype=torch.float16, device="cuda")
+        assert lib.ovmr_debug_gemm(0, 9, _p(A), _p(W), _p(b), None, None, _p(C), m, N, K, N, EPI_BIAS, 1.0, 0, 0, _s()) == 0
+        outs.append(C)
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0][:300], outs[2])
 
 
 @pytest.mark.parametrize("variant", [6, 8])

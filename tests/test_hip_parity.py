@@ -108,12 +108,14 @@ def test_layernorm_fold_on_off_vs_golden(golden):
     parity bar against the reference's recorded features, and next to each other."""
     g = golden("vitb16")
     e = _clip("ViT-B/16").engine(2)
-    img = torch.from_numpy(synth.images(8, 224, seed=1234))
+    # the reference's 8 recorded images in a batch of 24: a handful of images is a latency-bound shape, which runs the separate
+    # LayerNorm kernel whatever the option says (ovmr_api.hip can_fold_ln); a feature vector does not depend on its batch neighbours
+    img = torch.cat([torch.from_numpy(synth.images(8, 224, seed=1234)), torch.from_numpy(synth.images(16, 224, seed=4321))])
     out = {}
     try:
         for fold in (0, 1):
             e.set_option("ln_fold", fold)
-            out[fold] = e.encode_image(img, normalize=False).float().cpu().numpy()
+            out[fold] = e.encode_image(img, normalize=False).float().cpu().numpy()[:8]
             assert_cosine(out[fold], g["l1_fp16_image_features"], COS_TOL, f"ln_fold={fold} vs reference fp16 path")
             assert_cosine(out[fold], g["l1_fp32_image_features"], COS_TOL, f"ln_fold={fold} vs reference fp32 path")
     finally:
@@ -175,6 +177,42 @@ def test_prompt_learner_and_text_encoder_vs_golden(golden, name, key, tag, n_ctx
     out_v = te(torch.from_numpy(g[f"{tag}_pl_v_prompts"]).cuda(), torch.from_numpy(g[f"{tag}_pl_v_lens"]).cuda())
     assert_cosine(out_mm.float().cpu().numpy(), g[f"{tag}_te_mm"], COS_TOL, "TextEncoder(mm)")
     assert_cosine(out_v.float().cpu().numpy(), g[f"{tag}_te_v"], COS_TOL, "TextEncoder(v)")
+
+
+@pytest.mark.parametrize("name,n", [("small", 5), ("small", 40), ("ViT-B/16", 7), ("ViT-B/16", 125)])
+def test_text_groups_one_pass_equals_separate_passes(name, n):
+    """Engine.encode_text_groups (mm prompts + vision prompts + zero-shot ids in ONE pass of the text tower, each family with its own
+    truncated length; trainers/mm_classifier_one_prompt.py:200-212, :118-126) against the three single-family entry points: the
+    same arithmetic per sequence, so the rows agree up to the kernel choice the larger row count implies (1 - cos <= 1e-5), for a
+    handful of prompts (the 64 x 64 split-K GEMMs) and for a shard's worth (tile kernels with the LayerNorm fold)."""
+    cm = _clip(name)
+    e = cm.engine(2)
+    spec = synth.SPECS[name]
+    ids = torch.from_numpy(synth.class_token_ids(n, seed=99)).cuda()
+    eos = ids.argmax(-1).to(torch.int32)
+    max_eos = int(eos.max())
+    g = torch.Generator().manual_seed(n)
+    tokens = torch.randn((n, 2, spec.embed_dim), generator=g).cuda()
+    base = e.embed_tokens(ids)
+    vt = e.embed_tokens(torch.from_numpy(synth.template_token_ids(spec.context_length)).cuda())
+    mm = e.assemble_prompts(base, torch.arange(n, device="cuda"), tokens)
+    v = e.assemble_prompts(vt, None, tokens)
+    mm_l, v_l = eos + 2, torch.full((n,), 3, dtype=torch.int32, device="cuda")
+    want = [e.encode_text_embedded(mm, mm_l, max_eos + 3, normalize=2), e.encode_text_embedded(v, v_l, 4, normalize=2),
+            e.encode_text_ids(ids, max_eos + 1, normalize=1)]
+    got = e.encode_text_groups([dict(prompts=mm, index=mm_l, seq_len=max_eos + 3, normalize=2),
+                                dict(prompts=v, index=v_l, seq_len=4, normalize=2),
+                                dict(ids=ids, seq_len=max_eos + 1, normalize=1)])
+    for a, b, what in zip(got, want, ("mm", "v", "text")):
+        assert bool(torch.isfinite(a.float()).all())
+        assert_cosine(a.float().cpu().numpy(), b.float().cpu().numpy(), 1e-5, f"{what} rows, one pass vs separate passes")
+    # one group through the groups entry point IS the single-family call (which splits more than max_prompts = 64 sequences into
+    # chunks: other row counts, other kernels)
+    one = e.encode_text_groups([dict(ids=ids, seq_len=max_eos + 1, normalize=1)])[0]
+    assert torch.equal(one, want[2]) if n <= 64 else cosine_rows(one.float().cpu().numpy(), want[2].float().cpu().numpy()).min() >= 1 - 1e-5
+    # an empty group is skipped
+    got2 = e.encode_text_groups([dict(ids=ids[:0], seq_len=4, normalize=1), dict(ids=ids, seq_len=max_eos + 1, normalize=1)])
+    assert got2[0].shape == (0, spec.embed_dim) and torch.equal(got2[1], one)
 
 
 def _margin_ok_rows(logits, margin):
@@ -512,12 +550,20 @@ def test_cli_generate_and_evaluate_end_to_end(tmp_path, O):
     pl_sd = {k: torch.from_numpy(v) for k, v in synth.prompt_learner_state_dict(spec, 2, SEED, True).items()}
     checkpoint.save_prompt_learner_state(pl_sd, str(tmp_path / "ckpt"), 30)
     out = tmp_path / "out"
-    res = cli.main(["--root", str(root), "--clip-weights", str(tmp_path / "clip.pt"), "--bpe-path", bpe, "--eval-only",
-                    "--model-dir", str(tmp_path / "ckpt"), "--load-epoch", "30", "--output-dir", str(out),
-                    "--eval_mode", "fusion", "--eval_tau", "10", "--n_ctx", "2", "DATASET.NUM_SHOTS", str(S),
-                    "TEST.BATCH_SIZE", "6"])
+    # the reference's command line (scripts/mm_cls/generate_classifier.sh:30-44): a YAML config file with the reference's keys, the
+    # flags, trailing KEY VALUE opts in the reference's spelling
+    from test_next_rows_cpu import TRAINER_YAML
+    R = spec.image_resolution
+    yaml_text = TRAINER_YAML.replace("SIZE: (224, 224)", f"SIZE: ({R}, {R})").replace('NAME: "ViT-B/16"', 'NAME: ""').replace("BATCH_SIZE: 256", "BATCH_SIZE: 6")
+    (tmp_path / "trainer.yaml").write_text(yaml_text)
+    (tmp_path / "dataset.yaml").write_text('DATASET:\n  NAME: "ImageNet"\n')
+    common = ["--root", str(root), "--seed", "1", "--trainer", "MM_CLS_OP", "--dataset-config-file", str(tmp_path / "dataset.yaml"),
+              "--config-file", str(tmp_path / "trainer.yaml"), "--clip-weights", str(tmp_path / "clip.pt"), "--bpe-path", bpe,
+              "--model-dir", str(tmp_path / "ckpt"), "--load-epoch", "30", "--eval_mode", "fusion", "--eval_tau", "10", "--n_ctx", "2", "--eval-only"]
+    res = cli.main(common + ["--output-dir", str(out), "DATASET.NUM_SHOTS", str(S), "DATASET.SUBSAMPLE_CLASSES", "all"])
     assert {"accuracy", "error_rate", "macro_f1"} <= set(res) and 0.0 <= res["accuracy"] <= 100.0
-    assert res["pipeline_exemplar"]["images"] == C * S and res["pipeline_test"]["images"] == 2 * C      # the pipelined loader ran (8 workers)
+    assert res["pipeline_exemplar"]["images"] == C * S and res["pipeline_test"]["images"] == 2 * C      # the pipelined loader ran (8 workers, from the YAML)
+    assert res["pipeline_exemplar"]["workers"] == 8 and res["classnames"] == names
     for f in ("mm_classifiers.pt", "visual_tokens.pt", "acc_per_class.csv", "f1_per_class.csv"):
         assert (out / f).exists(), f
     saved = torch.load(out / "mm_classifiers.pt", map_location="cpu")
@@ -532,8 +578,24 @@ def test_cli_generate_and_evaluate_end_to_end(tmp_path, O):
         r = O.forward_prompt(img, lab, tok, _oracle_sd(O, "small"), pl_sd, 2, 10.0, 2, "fp16")
     for k in ("text_classifier", "vision_classifier", "mm_classifier"):
         assert_cosine(saved[k].numpy(), r[k].numpy(), COS_TOL, k)
-    assert cli.main(["--root", str(root), "--clip-weights", str(tmp_path / "clip.pt"), "--bpe-path", bpe, "--eval-only",
-                     "--output-dir", str(out)]) == {}          # "results exist ... skip this job"
+    assert cli.main(common + ["--output-dir", str(out)]) == {}          # "results exist ... skip this job"
+    # DATASET.SUBSAMPLE_CLASSES new: the second half of the classes (datasets/oxford_pets.py:141-202), relabelled from 0 -- a
+    # 2-row classifier file whose rows are the all-classes job's rows 2 and 3 (same exemplars: the draw precedes the subsampling)
+    out_new = tmp_path / "out_new"
+    res_new = cli.main(common + ["--output-dir", str(out_new), "DATASET.NUM_SHOTS", str(S), "DATASET.SUBSAMPLE_CLASSES", "new"])
+    assert res_new["classnames"] == names[2:] and res_new["pipeline_test"]["images"] == 2 * 2
+    saved_new = torch.load(out_new / "mm_classifiers.pt", map_location="cpu")
+    for k in ("text_classifier", "vision_classifier", "mm_classifier"):
+        assert saved_new[k].shape == (2, spec.embed_dim)
+        assert_cosine(saved_new[k].numpy(), saved[k][2:].numpy(), 1e-5, f"{k} rows of the `new` half")
+    assert saved_new["fusion_weight"].shape == (2, 3)
+    # a config that does not describe the model, or a key that does not exist, stops the job instead of being dropped
+    with pytest.raises(SystemExit):
+        cli.main(common + ["--output-dir", str(tmp_path / "o3"), "DATASET.NUM_SHOTS", str(S), "INPUT.SIZE", "(224, 224)"])
+    with pytest.raises(SystemExit):
+        cli.main(common + ["--output-dir", str(tmp_path / "o4"), "DATASET.NUM_SHOTS", str(S), "MODEL.BACKBONE.NAME", "ViT-B/16"])
+    with pytest.raises(KeyError):
+        cli.main(common + ["--output-dir", str(tmp_path / "o5"), "TEST.BATCH_SIZE", "6"])
 
 
 def test_config_c2_hundred_classes_eight_shots(O):
@@ -821,17 +883,32 @@ def test_encoder_chunk_is_whole_rounds_and_does_not_change_results():
         assert 768 * 3 // 4 <= auto768 <= 768
         e.finalize(64, 64, 256)
         assert e.encode_chunk == 64                                             # a reserve of less than two rounds is left alone
-        e.finalize(4, 64, 256)                                                  # 8 images against a workspace of 4: two launch sequences
-        img = torch.from_numpy(synth.images(8, spec.image_resolution, seed=5)).half().cuda()
+        e.finalize(16, 64, 256)                                                 # 32 images against a workspace of 16: two launch sequences
+        img = torch.from_numpy(synth.images(32, spec.image_resolution, seed=5)).half().cuda()
         want = e.encode_image(img, normalize=False).clone()
-        for c in (2, 4):                                                        # (chunks of >= 256 token rows: the same kernels as the whole batch)
+        assert e.encode_plan(32) == [16, 16]
+        e.set_option("enc_chunk", 8)                                            # (1576 token rows: the same tile kernels and LayerNorm fold as 16 images)
+        assert e.encode_chunk == 8 and e.encode_plan(32) == [8, 8, 8, 8]
+        assert torch.equal(e.encode_image(img, normalize=False), want)
+        for c in (1, 2, 4):                                                     # latency-bound sequences: 64 x 64 split-K GEMMs, separate LayerNorm -- other roundings
             e.set_option("enc_chunk", c)
-            assert e.encode_chunk == c
-            assert torch.equal(e.encode_image(img, normalize=False), want)
-        e.set_option("enc_chunk", 1)                                            # 197 rows: the small-matrix kernels, separate LayerNorm -- other roundings
-        assert_cosine(e.encode_image(img, normalize=False).float().cpu().numpy(), want.float().cpu().numpy(), COS_TOL, "chunks of one image")
+            assert_cosine(e.encode_image(img, normalize=False).float().cpu().numpy(), want.float().cpu().numpy(), 1e-5, f"chunks of {c} image(s)")
         e.set_option("enc_chunk", 0)
-        assert e.encode_chunk == 4
+        assert e.encode_chunk == 16
+        # a remainder of less than one round of tiles joins the last full sequence instead of becoming a launch sequence of its own
+        if n_cu == 256:
+            e.finalize(775, 64, 256)
+            assert e.encode_plan(800) == [800] and e.encode_plan(775 * 2 + 25) == [775, 800] and e.encode_plan(775 + 110) == [885]
+            assert e.encode_plan(775 + 111) == [775, 111] and e.encode_plan(775 + 500) == [775, 500] and e.encode_plan(700) == [700]
+        e.finalize(256, 64, 256)                                                # 2.3 rounds on the narrowest grid: fold slack = min(one round, 256 / 4) images
+        chunk = e.encode_chunk
+        plan = e.encode_plan(chunk + 20)
+        assert plan == [chunk + 20], plan
+        img = torch.from_numpy(synth.images(chunk + 20, spec.image_resolution, seed=6)).half().cuda()
+        got = e.encode_image(img, normalize=False)
+        parts = torch.cat([e.encode_image(img[:chunk], normalize=False), e.encode_image(img[chunk:], normalize=False)])
+        assert torch.equal(got[:chunk], parts[:chunk])                          # the same tile kernels for the first `chunk` images either way
+        assert_cosine(got.float().cpu().numpy(), parts.float().cpu().numpy(), 1e-5, "folded remainder vs its own launch sequence")
     finally:
         e.set_option("enc_chunk", 0)
         e.finalize(64, 64, 256)

@@ -128,6 +128,139 @@ def test_runner_helpers(tmp_path):
     a = cli.parse(["--root", "r", "--clip-weights", "w.pt", "--eval-only", "--load-epoch", "30", "--eval_tau", "5",
                    "DATASET.NUM_SHOTS", "8"])
     assert a.load_epoch == 30 and a.eval_tau == 5.0 and a.opts == ["DATASET.NUM_SHOTS", "8"]
+    # the reference's defaults (train.py:183-255), not this runner's old ones
+    assert a.eval_mode == "multimodal" and a.n_ctx is None and a.seed == -1 and a.trainer == "" and a.output_dir == ""
+
+
+# the keys of the reference's own YAML files (configs/trainers/MM_CLS_OP/vit_b16_c4_ep50_imagenet21k_pretrain.yaml,
+# configs/datasets/imagenet.yaml): the parser must take such a file as it is
+TRAINER_YAML = """
+DATALOADER:
+  TRAIN_X:
+    BATCH_SIZE: 1536
+    SAMPLER: "RandomClassSampler"
+    N_INS: 8
+  TEST:
+    BATCH_SIZE: 256
+    N_INS: 16
+  NUM_WORKERS: 8
+  K_TRANSFORMS: 1
+INPUT:
+  SIZE: (224, 224)
+  INTERPOLATION: "bicubic"
+  PIXEL_MEAN: [0.48145466, 0.4578275, 0.40821073]
+  PIXEL_STD: [0.26862954, 0.26130258, 0.27577711]
+  RRCROP_SCALE: (0.25, 1.0)
+  TRANSFORMS: ["random_resized_crop", "random_flip", 'colorjitter', 'gaussian_noise', "normalize"]
+OPTIM:
+  NAME: "adam"
+  LR: 0.0002
+  MAX_EPOCH: 30
+  WARMUP_CONS_LR: 1e-5
+TRAIN:
+  PRINT_FREQ: 10
+TEST:
+  NO_TEST: True
+MODEL:
+  BACKBONE:
+    NAME: "ViT-B/16"
+TRAINER:
+  COCOOP:
+    N_CTX: 2
+    CTX_INIT: " ?"
+    PREC: "fp16"
+"""
+
+
+def test_setup_cfg_layers_as_train_py(tmp_path):
+    """ovmr_amd.config.setup_cfg against train.py:134-155: defaults < dataset config file < config file < flags < trailing opts."""
+    from types import SimpleNamespace as NS
+    from ovmr_amd import config
+    (tmp_path / "trainer.yaml").write_text(TRAINER_YAML)
+    (tmp_path / "dataset.yaml").write_text('DATASET:\n  NAME: "ImageNet"\n  NUM_SHOTS: 4\nDATALOADER:\n  TEST:\n    BATCH_SIZE: 64\n')
+    base = dict(root="", output_dir="", seed=-1, trainer="", backbone="", init_weight="", n_ctx=None, eval_mode="multimodal",
+                eval_tau=None, dataset_config_file="", config_file="", opts=[])
+    # 1. nothing given: the reference's defaults
+    c = config.setup_cfg(NS(**base))
+    assert (c.EVAL_MODE, c.EVAL_TAU, c.TRAINER.COCOOP.N_CTX, c.DATALOADER.TEST.BATCH_SIZE, c.DATASET.NUM_SHOTS, c.SEED) == ("multimodal", 10, 16, 32, -1, -1)
+    assert c.DATASET.SUBSAMPLE_CLASSES == "all" and c.INPUT.INTERPOLATION == "bilinear" and c.INPUT.TRANSFORMS == ()
+    # 2. files: the config file wins over the dataset file, both over the defaults; literal strings are decoded
+    c = config.setup_cfg(NS(**{**base, "dataset_config_file": str(tmp_path / "dataset.yaml"), "config_file": str(tmp_path / "trainer.yaml")}))
+    assert c.DATALOADER.TEST.BATCH_SIZE == 256 and c.DATASET.NUM_SHOTS == 4 and c.DATASET.NAME == "ImageNet"
+    assert c.INPUT.SIZE == (224, 224) and c.INPUT.INTERPOLATION == "bicubic" and "normalize" in c.INPUT.TRANSFORMS
+    assert c.TRAINER.COCOOP.N_CTX == 2 and c.MODEL.BACKBONE.NAME == "ViT-B/16" and c.DATALOADER.NUM_WORKERS == 8
+    assert c.INPUT.PIXEL_MEAN == [0.48145466, 0.4578275, 0.40821073] and c.DATALOADER.TRAIN_X.N_INS == 8
+    # 3. + 4. flags (only truthy ones, reset_cfg), then the trailing opts -- generate_classifier.sh's own command line
+    c = config.setup_cfg(NS(**{**base, "config_file": str(tmp_path / "trainer.yaml"), "root": "./data", "seed": 1, "trainer": "MM_CLS_OP",
+                               "output_dir": "out", "eval_mode": "fusion", "eval_tau": 10, "n_ctx": 2,
+                               "opts": ["DATASET.NUM_SHOTS", "16", "DATASET.SUBSAMPLE_CLASSES", "new", "DATALOADER.TEST.BATCH_SIZE", "128"]}))
+    assert (c.DATASET.ROOT, c.SEED, c.TRAINER.NAME, c.OUTPUT_DIR, c.EVAL_MODE) == ("./data", 1, "MM_CLS_OP", "out", "fusion")
+    assert (c.DATASET.NUM_SHOTS, c.DATASET.SUBSAMPLE_CLASSES, c.DATALOADER.TEST.BATCH_SIZE) == (16, "new", 128)
+    c = config.setup_cfg(NS(**{**base, "config_file": str(tmp_path / "trainer.yaml"), "n_ctx": 0, "eval_tau": 0, "seed": 0}))
+    assert c.TRAINER.COCOOP.N_CTX == 2 and c.EVAL_TAU == 10 and c.SEED == -1                     # `if args.x:` -- falsy flags leave the cfg alone
+    # keys that do not exist raise (yacs: "Non-existent config key"), as does this runner's old spelling of the batch size
+    for bad in (["TEST.BATCH_SIZE", "6"], ["DATASET.SUBSAMPLE", "base"], ["FOO", "1"]):
+        with pytest.raises(KeyError):
+            config.setup_cfg(NS(**{**base, "opts": bad}))
+    with pytest.raises(ValueError):
+        config.setup_cfg(NS(**{**base, "opts": ["DATASET.SUBSAMPLE_CLASSES", "novel"]}))
+    with pytest.raises(ValueError):
+        config.setup_cfg(NS(**{**base, "opts": ["DATASET.NUM_SHOTS", "many"]}))                  # type mismatch with the default
+    with pytest.raises(ValueError):
+        config.setup_cfg(NS(**{**base, "opts": ["DATASET.NUM_SHOTS"]}))                          # odd override list
+    config.setup_cfg(NS(**{**base, "opts": ["OPTIM.LR", "0.1", "TRAIN.PRINT_FREQ", "5"]}))        # known, ignored on this path
+
+
+def test_subsample_classes_base_new(tmp_path):
+    """DATASET.SUBSAMPLE_CLASSES as datasets/oxford_pets.py:141-202 on a 5-class folder: `base` = the first ceil(5/2) = 3 labels,
+    `new` = the other 2, relabelled from 0 in sorted order, in the exemplar AND the test items; class names follow the labels."""
+    from types import SimpleNamespace as NS
+    from PIL import Image
+    from ovmr_amd import cli, config
+    rng = np.random.default_rng(0)
+    names = {"n05": "echidna", "n01": "tench", "n03": "stingray", "n02": "goldfish", "n04": "hen"}
+    for split, n in (("train", 4), ("val", 2)):
+        for folder in names:
+            d = tmp_path / split / folder
+            d.mkdir(parents=True)
+            for i in range(n):
+                Image.fromarray(rng.integers(0, 255, (20, 24, 3), dtype=np.uint8)).save(d / f"im{i}.png")
+    (tmp_path / "classnames.txt").write_text("".join(f"{k} {v}\n" for k, v in names.items()))
+    base = dict(root=str(tmp_path), output_dir="", seed=1, trainer="MM_CLS_OP", backbone="", init_weight="", n_ctx=2, eval_mode="fusion",
+                eval_tau=10, dataset_config_file="", config_file="")
+    got = {}
+    for sub in ("all", "base", "new"):
+        cfg = config.setup_cfg(NS(**base, opts=["DATASET.NUM_SHOTS", "3", "DATASET.SUBSAMPLE_CLASSES", sub]))
+        got[sub] = cli.build_splits(cfg)
+    ordered = ["tench", "goldfish", "stingray", "hen", "echidna"]                # sorted folders n01..n05
+    for sub, want in (("all", ordered), ("base", ordered[:3]), ("new", ordered[3:])):
+        classnames, ex, test = got[sub]
+        C = len(want)
+        assert classnames == want
+        assert [l for _, l in ex] == [c for c in range(C) for _ in range(3)]                       # 3 consecutive rows per class, labels 0..C-1
+        assert sorted({l for _, l in test}) == list(range(C)) and len(test) == 2 * C
+        folders_of = lambda items, lab: {p.split("/")[-2] for p, l in items if l == lab}
+        for c, nm in enumerate(want):                                                            # every label points at its own folder, in both splits
+            f = [k for k, v in names.items() if v == nm][0]
+            assert folders_of(ex, c) == {f} and folders_of(test, c) == {f}
+    # the draw precedes the subsampling: `base` / `new` exemplars are the same images the all-classes job draws
+    all_ex = {p for p, _ in got["all"][1]}
+    assert {p for p, _ in got["base"][1]} | {p for p, _ in got["new"][1]} == all_ex
+    # the function itself, on labels with a gap and an extra element per item
+    a = [("x", 7, "seven"), ("y", 2, "two"), ("z", 4, "four")]
+    b = [("t", 4, "four"), ("u", 7, "seven")]
+    ra, rb = config.subsample_classes(a, b, subsample="base")                                    # sorted labels 2, 4 | 7
+    assert ra == [("y", 0, "two"), ("z", 1, "four")] and rb == [("t", 1, "four")]
+    ra, rb = config.subsample_classes(a, b, subsample="new")
+    assert ra == [("x", 0, "seven")] and rb == [("u", 0, "seven")]
+    with pytest.raises(AssertionError):
+        config.subsample_classes(a, subsample="novel")
+    # an exemplar list reproduces a given few-shot set (labels before subsampling)
+    lst = tmp_path / "few.txt"
+    lst.write_text("".join(f"{p} {l + 3}\n" for p, l in got["new"][1]))
+    cfg = config.setup_cfg(NS(**base, opts=["DATASET.NUM_SHOTS", "3", "DATASET.SUBSAMPLE_CLASSES", "all"]))
+    with pytest.raises(SystemExit):
+        cli.build_splits(cfg, exemplar_list=str(lst))                                           # classes without exemplars
 
 
 def test_loader_list_form_k_transforms():
