@@ -704,10 +704,11 @@ def effective_cpus():
 
 
 def cpu_baseline(spec, sd, pl, tok, args, n_ctx):
-    """The oracle (torch-CPU port of the reference path) on the WHOLE host: cores // threads worker processes x `--cpu-threads`
-    threads (a single 256-thread pool is far slower than 16-thread pools on this path), disjoint class slices of
+    """The oracle (torch-CPU port of the reference path) on the CPUs THIS PROCESS MAY USE -- the affinity mask capped by the cgroup
+    quota (`effective_cpus`: 16 of the 256 hardware threads on the GPU boxes), not the whole host: usable // threads worker processes x
+    `--cpu-threads` threads (a single 256-thread pool is far slower than 16-thread pools on this path), disjoint class slices of
     `--cpu-sample-classes` classes x shots (batch 32 at the defaults), 1 warm-up + `--cpu-reps` timed repetitions, median.
-    Whole-host images/s = sum over workers of images per repetition / median repetition time, all workers running together.
+    images/s = sum over workers of images per repetition / median repetition time, all workers running together.
     Reported: the faster of fp32-math-on-fp16-rounded-weights and fp16."""
     import statistics
     import torch

@@ -49,11 +49,13 @@ def build(verbose: bool = True, force: bool = False, experiments: bool = False) 
     flags = FLAGS + (["-DOVMR_EXPERIMENTS"] if experiments else [])
     os.makedirs(OBJ, exist_ok=True)
     srcs = sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
+    if experiments:                                     # csrc/experiments/: kernels that exist for their measurements only (attention variants 4 and 6)
+        srcs += sorted(os.path.join("experiments", f) for f in os.listdir(os.path.join(CSRC, "experiments")) if f.endswith(".hip"))
     hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     hdrs.append(os.path.join(os.path.dirname(HERE), "include", "ovmr_hip.h"))
     jobs = []
     for f in srcs:
-        src, obj = os.path.join(CSRC, f), os.path.join(OBJ, f[:-4] + ".o")
+        src, obj = os.path.join(CSRC, f), os.path.join(OBJ, os.path.basename(f)[:-4] + ".o")
         if force or _stale(obj, [src] + hdrs):
             jobs.append([HIPCC, *flags, "-c", src, "-o", obj])
 
@@ -67,7 +69,7 @@ def build(verbose: bool = True, force: bool = False, experiments: bool = False) 
 
     with ThreadPoolExecutor(max_workers=min(4, max(1, len(jobs)))) as ex:
         list(ex.map(run, jobs))
-    objs = [os.path.join(OBJ, f[:-4] + ".o") for f in srcs]
+    objs = [os.path.join(OBJ, os.path.basename(f)[:-4] + ".o") for f in srcs]
     if force or jobs or _stale(LIB, objs):
         run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB])
     return LIB

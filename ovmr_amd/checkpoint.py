@@ -47,14 +47,23 @@ def prompt_learner_checkpoint_path(directory: str, epoch: Optional[int] = None, 
 
 
 def _torch_load(path: str):
-    """Tensors, ints and dicts are all these files need: unpickle with weights_only=True, and fall back to full unpickling (which
-    can execute code from the file -- what the reference's load_checkpoint always does) only when that fails, with a warning."""
+    """Tensors, ints and dicts are all the hot path reads from these files, so they are unpickled with weights_only=True: nothing in
+    the file can run code.  Checkpoints written by the reference's save_checkpoint also pickle the optimiser state and Dassl's
+    scheduler OBJECTS (the warm-up scheduler and its `successor`), which weights_only refuses.  Such a file is loaded only when the
+    caller says it is trusted -- OVMR_TRUSTED_CHECKPOINTS=1 in the environment -- because full unpickling executes whatever the file
+    asks for (what the reference's load_checkpoint always does, Dassl.pytorch/dassl/utils/torchtools.py:66-97); otherwise this raises
+    with the way out."""
     import pickle
-    import warnings
     try:
         return torch.load(path, map_location="cpu", weights_only=True)
     except (pickle.UnpicklingError, RuntimeError) as e:
-        warnings.warn(f'"{path}" needs full unpickling ({str(e).splitlines()[0][:120]}); loading it with weights_only=False')
+        why = str(e).splitlines()[0][:160]
+        if os.environ.get("OVMR_TRUSTED_CHECKPOINTS", "0") != "1":
+            raise RuntimeError(f'"{path}" holds pickled objects beyond tensors ({why}).  Loading it means FULL unpickling, which can '
+                               "execute code from the file: set OVMR_TRUSTED_CHECKPOINTS=1 if you trust where it came from, or "
+                               "re-save its state_dict alone (torch.save({'state_dict': ckpt['state_dict'], 'epoch': ...}))") from e
+        import warnings
+        warnings.warn(f'"{path}" needs full unpickling ({why}); OVMR_TRUSTED_CHECKPOINTS=1: loading it with weights_only=False')
         return torch.load(path, map_location="cpu", weights_only=False)
 
 

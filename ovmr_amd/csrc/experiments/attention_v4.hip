@@ -21,7 +21,7 @@
 // B operands of 7 PV steps, row sums from the matrix pipe.
 // Compiled into the EXPERIMENT build only (python -m ovmr_amd.build --experiments): same speed as variant 3, kept as the vehicle of the ablations.
 #ifdef OVMR_EXPERIMENTS
-#include "attn_single_pass.h"
+#include "../attn_single_pass.h"
 
 #include <algorithm>
 

@@ -21,7 +21,7 @@
 // issue vector work faster (tools/valu_rate.hip: v_exp_f32 6.3 cycles per SIMD at four waves, 8.3 at two; v_fma_f32 1.9 / 2.6) and
 // cover each other's waits better than two waves with two tiles.  Experiment build only (variants 60 + mode).
 #ifdef OVMR_EXPERIMENTS
-#include "common.h"
+#include "../common.h"
 
 #include <algorithm>
 #include <type_traits>

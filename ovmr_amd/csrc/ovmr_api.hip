@@ -40,9 +40,11 @@ struct ovmr_handle {
     std::vector<void*> derived;   // layouts rebuilt by every ovmr_finalize
     std::string err;
     bool finalized = false;
-    int gelu_exact = 0;
-    int last_q_cls = 1;           // last vision block: Q projected for the CLS rows only (batches of >= 256 images)
-    int fuse_im2col = 1;          // patch rows gathered by the patch-embedding GEMM itself (fp16 images, 16 x 16 patches)                       // 0: one-rounding fp32 QuickGELU in the c_fc epilogue (common.h quick_gelu_f32x2); 1: the reference's three fp16 rounding points
+    int gelu_exact = 0;           // 0 (default): one-rounding fp32 QuickGELU in the c_fc epilogue (common.h quick_gelu_f32x2) -- DEVIATES from the
+                                  // reference's fp16 rounding points by up to 8e-3 * max(1, |g|) per value, 6e-7 in 1 - cos end to end (INTEGRATION.md,
+                                  // DESIGN.md section 3); 1: the reference's three fp16 rounding points
+    int last_q_cls = 1;           // last vision block: Q projected for the CLS rows only (launch sequences of >= 256 images)
+    int fuse_im2col = 1;          // patch rows gathered by the patch-embedding GEMM itself (fp16 images, 16 x 16 patches)
     int gemm_variant = 8, attn_variant = 3;   // defaults = fastest verified kernels (tools/gemm_bench.py, tools/attn_bench.py); attention 3 falls back to 1 / 0 by shape
     int ln_fold = 1;                          // fold ln_1 / ln_2 of the fp16 towers into the consuming GEMM where the shape allows
     int xval_fused = 1;                       // cross-validation logits: row argmax fused into the GEMM epilogue (never stored)
@@ -868,10 +870,12 @@ double ovmr_flops_per_image_executed(const ovmr_handle* h) {
     if (!h) return 0;
     const ovmr_model_desc& d = h->d;
     const double L = h->L, W = d.vision_width;
-    // last block as launched (batches of >= 256 images): K/V projection of all tokens (4 L W^2), Q of the CLS row (2 W^2), then one
-    // query row: scores + PV (4 L W), out_proj (2 W^2), MLP (16 W^2)
+    // last block as launched: K/V projection of all tokens (4 L W^2), then one query row: scores + PV (4 L W), out_proj (2 W^2),
+    // MLP (16 W^2).  Q: for the CLS row alone (2 W^2) where the launch sequences hold >= 256 images and last_q_cls is set (what
+    // ovmr_encode_image does for a reserve of that size), else for every token (2 L W^2)
+    const bool q_cls = h->last_q_cls && (!h->finalized || std::min(h->max_images, h->enc_chunk > 0 ? h->enc_chunk : h->max_images) >= 256);
     const double last_full = 24.0 * L * W * W + 4.0 * L * L * W;
-    const double last_run = 4.0 * L * W * W + 4.0 * L * W + 20.0 * W * W;
+    const double last_run = 4.0 * L * W * W + 4.0 * L * W + 18.0 * W * W + (q_cls ? 2.0 * W * W : 2.0 * L * W * W);
     return ovmr_flops_per_image(h) - last_full + last_run;
 }
 double ovmr_flops_per_prompt(const ovmr_handle* h, int seq_len) {

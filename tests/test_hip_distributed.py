@@ -82,3 +82,24 @@ def test_bench_line_proves_its_process_group(tmp_path):
     assert d["backend"] == "nccl" and d["collective_library"] == "RCCL" and d["ranks"] == 1 and d["devices_seen"] == 1
     assert len(d["device_ids"]) == 1 and d["rccl_version"] and d["rccl_version"][0].isdigit()
     assert lines["dist"]["n_gpus"] == 1 and lines["dist"]["value"] > 0
+
+
+@pytest.mark.timeout(900)
+def test_emulated_world_projection_runs_the_sharded_path(tmp_path):
+    """`bench.py --emulate-world 2`: the whole job as one rank, then each rank's shard alone through the SHARDED code path (the two
+    collectives served from the other rank's recorded contribution) -- a record with one entry per rank, shards that add up to the job,
+    a projected speed-up between 1 and the rank count, labelled a projection.  Small job: 12 classes x 4 shots + 32 queries."""
+    import json
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(repo, "bench.py"), "--classes", "12", "--shots", "4", "--queries", "32", "--query-batch", "16",
+           "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--emulate-world", "2"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith('{"metric')][-1])
+    assert d["projection"] is True and d["emulated_world"] == 2 and "PROJECTION" in d["metric"]
+    per = d["per_rank"]
+    assert [p["rank"] for p in per] == [0, 1]
+    assert sum(p["classes"] for p in per) == 12 and sum(p["exemplar_images"] for p in per) == 48 and sum(p["query_images"] for p in per) == 32
+    assert all(p["ms_per_step"] > 0 for p in per) and d["slowest_rank_ms"] == max(p["ms_per_step"] for p in per)
+    assert 0.5 < d["projected_speedup"] <= 2.0 + 1e-6 or d["whole_job_ms_one_rank"] < 30.0      # (a toy job is launch-bound: no speed-up to expect)
+    assert d["collective_payload_bytes"]["all_reduce_counts"] == 3 * 2 * 12 * 4

@@ -317,6 +317,32 @@ def test_reference_written_checkpoint_files():
         checkpoint.load_prompt_learner_state(CKPT, 7)
 
 
+class _SchedulerLike:
+    """Stands for the objects Dassl pickles next to the weights (the warm-up scheduler and its `successor`)."""
+    def __init__(self):
+        self.last_epoch = 30
+
+
+def test_full_unpickling_is_opt_in(tmp_path, monkeypatch):
+    """A checkpoint that pickles OBJECTS (what the reference's save_checkpoint writes: scheduler instances) is refused unless
+    OVMR_TRUSTED_CHECKPOINTS=1 says its origin is trusted; a tensors-only file never needs the opt-in."""
+    from ovmr_amd import checkpoint
+    pl = {k: torch.from_numpy(v) for k, v in synth.prompt_learner_state_dict(synth.SPECS["micro"], 2, 11, True).items()}
+    d = tmp_path / "prompt_learner"
+    d.mkdir()
+    torch.save({"state_dict": pl, "epoch": 30, "scheduler": _SchedulerLike()}, d / "model.pth.tar-30")
+    monkeypatch.delenv("OVMR_TRUSTED_CHECKPOINTS", raising=False)
+    with pytest.raises(RuntimeError, match="OVMR_TRUSTED_CHECKPOINTS"):
+        checkpoint.load_prompt_learner_state(str(tmp_path), 30)
+    monkeypatch.setenv("OVMR_TRUSTED_CHECKPOINTS", "1")
+    with pytest.warns(UserWarning, match="full unpickling"):
+        got = checkpoint.load_prompt_learner_state(str(tmp_path), 30)
+    assert all(torch.equal(got[k], pl[k]) for k in pl)
+    monkeypatch.delenv("OVMR_TRUSTED_CHECKPOINTS")
+    torch.save({"state_dict": pl, "epoch": 31, "scheduler": None}, d / "model.pth.tar-31")
+    assert sorted(checkpoint.load_prompt_learner_state(str(tmp_path), 31)) == sorted(pl)
+
+
 def test_default_tokenizer_from_environment(tmp_path, monkeypatch):
     """CustomCLIP(cfg, classnames, clip_model) -- the reference's three-argument form -- finds its tokenizer through
     OVMR_BPE_PATH; without a table the error says what to do."""

@@ -28,6 +28,8 @@ def main():
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--zeros", action="store_true", help="zero-filled operands: shows how much of the time is clock/power (cdna guide rule 25)")
     ap.add_argument("--ldpad", type=int, default=0, help="row padding (halves) of A and W: stride experiment")
+    ap.add_argument("--shapes", default="", help="comma-separated shape names to run (default: all) -- one name per profiler pass gives per-shape "
+                    "counters for launches that share a kernel instantiation AND a grid (out_proj / c_proj: tools/pmc_gemm.sh)")
     ap.add_argument("--exp", action="store_true", help="time libovmr_hip_exp.so (experiment build) instead of the product library")
     args = ap.parse_args()
     if args.ldpad:
@@ -43,7 +45,10 @@ def main():
     p = lambda t: ctypes.c_void_p(t.data_ptr())
     s = lambda: ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     out = {}
+    only = {x for x in args.shapes.split(",") if x}
     for name, m, n, k, epi in shapes:
+        if only and name not in only:
+            continue
         g = torch.Generator(device=dev).manual_seed(1)
         A = (torch.randn((m + 256, k + args.ldpad), generator=g, device=dev) * 0.5).half()   # slack rows: blocked-layout experiment
         W = (torch.randn((n + 256, k + args.ldpad), generator=g, device=dev) * k ** -0.5).half()

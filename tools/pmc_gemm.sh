@@ -6,25 +6,33 @@
 # usage: tools/pmc_gemm.sh <variant> <outdir> [batch]
 V=${1:-6}; OUT=${2:-gpurun_out/pmc}; B=${3:-512}; R=${GRAFT_REPO_ROOT:-$(pwd)}
 mkdir -p $R/$OUT; cd /tmp; export TMPDIR=/tmp
-run() { name=$1; shift; timeout 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $R/$OUT/$name -- python3 $R/tools/gemm_bench.py --variants $V --rounds 1 --reps 2 --batch $B > $R/$OUT/$name.log 2>&1; }
+# SHAPES: "" = every shape of gemm_bench.py in one process (kernels keyed by name + grid); a shape name = that shape alone, keyed
+# "... shape=<name>": out_proj (K = 768) and c_proj (K = 3072) share one instantiation <3, 8, 17> AND one grid, so only separate
+# passes tell them apart (r04).
+run() { name=$1; shift; timeout 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $R/$OUT/$name$TAG -- python3 $R/tools/gemm_bench.py --variants $V --rounds 1 --reps 2 --batch $B --shapes "$SHAPE" > $R/$OUT/$name$TAG.log 2>&1; }
+for SHAPE in "" ${PMC_SHAPES:-out_proj c_proj out_proj_st c_proj_st}; do
+TAG=${SHAPE:+_$SHAPE}
 run fetch FETCH_SIZE
 run write WRITE_SIZE TCC_HIT_sum TCC_MISS_sum
 run sq1 SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES GRBM_GUI_ACTIVE
 run sq2 SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_VALU SQ_ACTIVE_INST_VALU
+done
 cd $R
 python3 - <<PY
 import csv, glob, collections, json, sys
 sys.path.insert(0, ".")
 from ovmr_amd.build import source_sha16
 out = collections.defaultdict(dict)
-for name in ("fetch", "write", "sq1", "sq2"):
-    for f in glob.glob("$OUT/%s/**/*counter_collection.csv" % name, recursive=True):
+import os
+shapes = [""] + "${PMC_SHAPES:-out_proj c_proj out_proj_st c_proj_st}".split()
+for name, shape in [(n, sh) for sh in shapes for n in ("fetch", "write", "sq1", "sq2")]:
+    for f in glob.glob("$OUT/%s%s/**/*counter_collection.csv" % (name, "_" + shape if shape else ""), recursive=True):
         agg = collections.defaultdict(lambda: collections.defaultdict(list))
         for r in csv.DictReader(open(f)):
             k = r["Kernel_Name"]
             if "gemm" not in k:
                 continue
-            key = k.split("::")[-1].split("(")[0] + " grid=" + r["Grid_Size"]
+            key = k.split("::")[-1].split("(")[0] + " grid=" + r["Grid_Size"] + (" shape=" + shape if shape else "")
             agg[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
             agg[key]["duration_us_under_pmc"].append((float(r["End_Timestamp"]) - float(r["Start_Timestamp"])) / 1e3)
         for key, c in agg.items():
