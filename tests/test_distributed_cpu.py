@@ -69,6 +69,11 @@ class OracleEngine:
             t = self.O.l2_normalize(t)
         return t
 
+    def encode_text_groups(self, groups):
+        """One pass over several prompt families = the per-family calls (a sequence does not depend on its neighbours)."""
+        return [self.encode_text_ids(g["ids"], g.get("seq_len"), g.get("normalize", 0)) if g.get("ids") is not None else
+                self.encode_text_embedded(g["prompts"], g["index"], g.get("seq_len"), g.get("normalize", 0)) for g in groups]
+
     def xval_counts(self, feats, labels, clf, tp, n_pred):
         lg = (self.logit_scale * (feats @ clf.t())).float()
         pred = lg.argmax(1)
