@@ -743,6 +743,41 @@ def test_config_c4_sixty_four_shots(O):
 
 
 @pytest.mark.timeout(900)
+@pytest.mark.parametrize("name,n_img", [("ViT-B/32", 5), ("ViT-B/32", 300), ("ViT-L/14", 3)])
+def test_other_clip_backbones_vs_oracle(O, name, n_img):
+    """The reference's other ViT checkpoints (configs/trainers/MM_CLS_OP/vit_b32_*.yaml: ViT-B/32 -- 32 x 32 patches, K = 3072, 50
+    tokens: the im2col pass and the short-sequence attention kernel; ViT-L/14 at 224 px -- 257 tokens, patch 14: attention variant 5 in
+    three-wave workgroups, width-1024 LayerNorm fold): image features of a few images (and, for 300 images, of the FIRST four against the
+    oracle -- the others only have to be finite and batch-independent) and text features against the oracle."""
+    from ovmr_amd import modules
+    spec = synth.SPECS[name]
+    sd_np = synth.clip_state_dict(spec, SEED, jitter=True)
+    cm = modules.CLIPModel({k: torch.from_numpy(v) for k, v in sd_np.items()}, spec)
+    e = cm.engine(2)
+    e.load_state_dict({}, {k: torch.from_numpy(v) for k, v in synth.prompt_learner_state_dict(spec, 2, SEED, True).items()})
+    e._pl_loaded = True
+    e.finalize(max(8, n_img), 8, 8)
+    img = torch.from_numpy(synth.images(n_img, spec.image_resolution, seed=8))
+    ids = torch.from_numpy(synth.class_token_ids(3, seed=8))
+    f = e.encode_image(img, normalize=True).float().cpu()
+    t = e.encode_text_ids(ids, normalize=1).float().cpu()
+    sd = O.convert_weights(O.to_torch(sd_np), "fp16")
+    torch.set_num_threads(min(32, os.cpu_count()))
+    k = min(n_img, 4)
+    with torch.no_grad():
+        rf = O.l2_normalize(O.encode_image(img[:k].half(), sd)).float()
+        rt = O.l2_normalize(O.encode_text(ids, sd)).float()
+    assert bool(torch.isfinite(f).all())
+    assert_cosine(f[:k].numpy(), rf.numpy(), COS_TOL, f"{name} image features")
+    assert_cosine(t.numpy(), rt.numpy(), COS_TOL, f"{name} text features")
+    if n_img > k:                                            # the same images in another batch composition: the tile kernels' rows are independent
+        again = e.encode_image(torch.cat([img[k:], img[:k]]), normalize=True).float().cpu()
+        assert_cosine(again[-k:].numpy(), f[:k].numpy(), 1e-5, f"{name}: features do not depend on the batch position")
+    del e, cm
+    torch.cuda.empty_cache()
+
+
+@pytest.mark.timeout(900)
 def test_config_c5_vit_l14_336_encode(O):
     """BASELINE config 5 architecture (ViT-L/14@336: 24 layers, width 1024, 577 tokens, patch 14 -> K = 588 padded to
     640, text width 768): image and text features of 2 inputs against the oracle."""
