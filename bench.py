@@ -395,27 +395,28 @@ def emulate_world(args, model, spec, dev):
         torch.cuda.synchronize()
         return (time.perf_counter() - t0) / args.steps
 
-    def queries(q):
-        out = None
+    def queries(q, collect=False):
+        out, outs = None, []
         for out in model.forward_batches((q[b:b + args.query_batch] for b in range(0, q.shape[0], args.query_batch)),
                                          stable_inputs=True, overlap=ov):
-            pass
-        return out
+            if collect:
+                outs.append(out.clone())
+        return torch.cat(outs) if collect and outs else out
 
     # ---- T(1 rank): the whole job, exactly bench.py's default step
     full_loader = ResidentEvalSet(ex_all, torch.arange(C, device=dev), S, args.classes_per_batch, presharded=True)
 
-    def whole():
+    def whole(collect=False):
         if not args.stream_text:
             model.zero_shot_classifier = model.prompt_learner.zero_shot_classifier = \
                 model.prompt_learner.encode_zero_shot(model.tokenized_prompts)
         model.forward_prompt(full_loader)
-        return queries(q_all)
+        return queries(q_all, collect)
 
     t1 = timed(whole)
     ref = {k: getattr(model, k).clone() for k in ("mm_classifier", "visual_classifer", "zero_shot_classifier", "fusion_weight", "visual_tokens")}
     counts_full = model.xval_counts.clone()
-    ref_out_all = whole().clone()
+    ref_out_all = whole(collect=True)
 
     # ---- every rank's shard, alone
     bound = local_class_bound(C, N, True, max(1, args.batch // S))
@@ -437,14 +438,14 @@ def emulate_world(args, model, spec, dev):
         emu.peer_blocks = peer_blocks
         model._dist, model._text_streamed = emu, True
 
-        def shard_step():
+        def shard_step(collect=False):
             model.forward_prompt(loader)
-            return queries(q)
+            return queries(q, collect)
 
         shard_step()                                        # records this rank's own votes
         emu.peer_counts = counts_full - emu.local_counts
         tr = timed(shard_step)
-        out = shard_step()
+        out = shard_step(collect=True)
         torch.cuda.synchronize()
         tg = time.perf_counter(); model.forward_prompt(loader); torch.cuda.synchronize(); tg = time.perf_counter() - tg
         # this rank's OWN rows against the whole job's rows for the same classes (the other ranks' rows are the recorded ones): equal
