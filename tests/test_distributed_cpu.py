@@ -214,3 +214,49 @@ def test_local_class_bound_covers_round_robin_batches():
                     sizes = [min(cpb, C - i * cpb) for i in range(nb)]
                     worst = max(sum(sizes[i] for i in shard_batches(nb, r, world)) for r in range(world))
                     assert worst <= local_class_bound(C, world, False, cfg_cpb), (C, world, cfg_cpb, cpb)
+
+
+def test_emulated_peers_reproduce_the_sharded_job():
+    """bench.py --emulate-world rests on `bench.EmulatedPeers`: rank r of N runs the SHARDED code path of forward_prompt alone, the two
+    collectives answered from the other ranks' recorded contributions.  On the CPU stand-in engine: for every rank of a 3-rank job
+    (ragged: 7 classes = 3 + 2 + 2) the emulated run must end with the whole job's classifier rows, tokens, counters and fusion weights --
+    the same result the real multi-process run above ends with."""
+    sys.path.insert(0, REPO)
+    import bench
+    from ovmr_amd import modules
+    from ovmr_amd.data import ResidentEvalSet
+    from ovmr_amd.shard import local_class_bound, pack_block, shard_range
+    torch.set_num_threads(2)
+    spec, C, world = synth.SPECS["tiny"], 7, 3
+    cfg = modules.make_cfg(n_ctx=N_CTX, num_shots=S, output_dir="")
+    pl = {k: torch.from_numpy(v) for k, v in synth.prompt_learner_state_dict(spec, N_CTX, SEED, True).items()}
+    tok = torch.from_numpy(synth.class_token_ids(C, seed=4321))
+    model = modules.CustomCLIP(cfg, tok, FakeCLIPModel(spec), prompt_learner_state=pl, reserve=(8, 8, 8), stream_text=True)
+    labels = np.repeat(np.arange(C), S)
+    img = torch.from_numpy(synth.images(C * S, spec.image_resolution, 1234, labels, 0.6))
+    # (one class per loader batch everywhere: torch's CPU GEMMs are not batch-invariant, the HIP kernels' rows are)
+    model.forward_prompt(ResidentEvalSet(img, torch.arange(C), S, 1, presharded=True))          # the whole job, one process
+    ref = {k: getattr(model, k).clone() for k in ("mm_classifier", "visual_classifer", "zero_shot_classifier", "fusion_weight", "visual_tokens")}
+    counts_full = model.xval_counts.clone()
+    bound = local_class_bound(C, world, True, 1)
+    blocks = []
+    for r in range(world):
+        a, b = shard_range(C, r, world)
+        loc = torch.arange(a, b)
+        blocks.append(pack_block(torch.cat([ref["mm_classifier"][loc], ref["visual_classifer"][loc], ref["zero_shot_classifier"][loc],
+                                            ref["visual_tokens"][loc].flatten(1)], dim=1), loc, bound))
+    peer_blocks = torch.cat(blocks)
+    for r in range(world):
+        a, b = shard_range(C, r, world)
+        emu = bench.EmulatedPeers(r, world)
+        emu.peer_blocks = peer_blocks
+        model._dist, model._text_streamed = emu, True
+        loader = ResidentEvalSet(img[a * S:b * S], torch.arange(a, b), S, 1, presharded=True)
+        model.forward_prompt(loader)                                  # records this rank's own votes
+        assert int(emu.local_counts[:, 1].sum()) == 3 * (b - a) * S   # every one of its rows voted once per classifier
+        emu.peer_counts = counts_full - emu.local_counts
+        model.forward_prompt(loader)
+        for k in ref:
+            assert torch.equal(getattr(model, k), ref[k]), f"rank {r}: {k}"
+        assert torch.equal(model.xval_counts, counts_full), f"rank {r}: counters"
+    model._dist = None

@@ -45,6 +45,26 @@ for (M, N, K, epi) in ((4096, 1024, 768, 2), (5500, 768, 3072, 3), (2500, 2304, 
             mism += 1
     bad += mism
     print(f"gemm variant 8 {(M, N, K, epi)}: {reps} launches, {mism} differ from the first", flush=True)
+# (round 4: the 64 x 64 split-K kernel -- four waves' partial tiles summed through LDS behind ONE barrier, prefetch depths 1 / 3 / 4 -- on
+#  latency-bound shapes incl. the in-place residual epilogue; variant 9 forces it)
+for (M, N, K, epi) in ((40, 512, 2048, 3), (775, 768, 3072, 3), (1500, 512, 512, 1), (256, 3072, 768, 2), (65, 130, 384, 1), (63, 72, 640, 3), (2000, 100, 512, 5)):
+    g = torch.Generator(device="cuda").manual_seed(M + N)
+    A = (torch.randn((M, K), generator=g, device="cuda") * 0.5).half()
+    W = (torch.randn((N, K), generator=g, device="cuda") * K ** -0.5).half()
+    b = (torch.randn((N,), generator=g, device="cuda") * 0.1).half()
+    res = torch.randn((M, N), generator=g, device="cuda").half()
+    ref, C, mism = None, torch.empty_like(res), 0
+    for rep in range(a.reps):
+        C.copy_(res)
+        if rep % 3 == 0:
+            junk.add_(1.0)
+        assert lib.ovmr_debug_gemm(0, 9, p(A), p(W), p(b), p(C) if epi == 3 else None, None, p(C), M, N, K, N, epi, 10.0, 0, 0, s()) == 0
+        if ref is None:
+            ref = C.clone()
+        elif not torch.equal(C, ref):
+            mism += 1
+    bad += mism
+    print(f"gemm split-K (variant 9) {(M, N, K, epi)}: {a.reps} launches, {mism} differ from the first", flush=True)
 # (variant 5: the 32x32x16 flash kernel of the ViT-L lengths -- asm LDS-DMA into a two-stage ring, one barrier per key block, 3- and 4-wave workgroups)
 for variant, shapes in ((3, ((512, 197, 12), (37, 197, 12), (3, 208, 4), (300, 193, 12))),
                         (5, ((64, 577, 16), (5, 577, 3), (96, 257, 16), (7, 300, 5), (9, 288, 1)))):
