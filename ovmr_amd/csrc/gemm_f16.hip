@@ -129,6 +129,9 @@ int launch_t128(const GemmArgs& a, hipStream_t s) {
 }  // namespace
 
 int launch_gemm_f16_v5(const GemmArgs& a, int variant, hipStream_t s);  // gemm_f16_v5.hip: 256(128)x256x64 LDS-DMA tiles, fused epilogues
+#ifdef OVMR_EXPERIMENTS
+int launch_gemm_f16_w2(const GemmArgs& a, hipStream_t s);               // experiments/gemm_f16_w2.hip
+#endif
 int launch_gemm_f16_small(const GemmArgs& a, hipStream_t s);            // gemm_f16_small.hip: 64x64 tiles, K split over the waves (latency-bound shapes)
 
 // Shapes that are at most ONE round of 64 x 64 tiles on the 256 CUs: there the K loop of a tile kernel runs at one memory latency
@@ -151,7 +154,7 @@ int launch_gemm_f16(const GemmArgs& a_in, int variant, hipStream_t s) {
     }
     if (a.M <= 0 || a.N <= 0) return 0;
     if (a.K <= 0 || (a.K % BK) != 0 || (a.lda & 7) || (a.ldw & 7)) return -2;  // caller pads K to 64
-    const int v5 = (variant == 0 || variant == 9 || variant == 7) ? 8 : variant;
+    const int v5 = (variant == 0 || variant == 9 || variant == 7 || variant == 10) ? 8 : variant;
     if (a.im2col_R) {                                                           // only the v5 kernel gathers patch rows from the image; -4: shape not supported
         const int rc = launch_gemm_f16_v5(a, v5, s);
         return rc == -100 ? -4 : rc;
@@ -164,6 +167,13 @@ int launch_gemm_f16(const GemmArgs& a_in, int variant, hipStream_t s) {
         const int rc = launch_gemm_f16_v5(a, v5, s);
         return rc == -100 ? -4 : rc;
     }
+#ifdef OVMR_EXPERIMENTS
+    if (variant == 10) {                    // experiments/gemm_f16_w2.hip: 256 x 128 tiles, two workgroups per CU (timing experiment, r04)
+        const int rc = launch_gemm_f16_w2(a, s);
+        if (rc != -100) return rc;
+        variant = 8;
+    }
+#endif
     if (variant == 7) variant = 8;          // A/B: variant 8 without the split-K kernel (the caller's LayerNorm-fold rule keys on 8 as well)
     else if (variant == 9 || (variant == 8 && gemm_f16_is_small(a.M, a.N))) {
         const int rc = launch_gemm_f16_small(a, s);
