@@ -215,6 +215,53 @@ def test_text_groups_one_pass_equals_separate_passes(name, n):
     assert got2[0].shape == (0, spec.embed_dim) and torch.equal(got2[1], one)
 
 
+def test_text_groups_ragged_compositions_and_workspace_fallback():
+    """ovmr_encode_text_groups on compositions the head never produces: groups of different sizes (1 ... 70 prompts), full-length
+    sequences (seq_len = 77) beside 3-token ones, id groups and embedded groups in any order -- every row equal (1 - cos <= 1e-5) to
+    the single-family entry points; and a composition whose token rows exceed the workspace (4 x 200 full-length prompts on a handle
+    finalised for 4 prompts: ~290 MB against the 192 MB logits floor of the arena) falls back to one chunked pass per group, results unchanged."""
+    from ovmr_amd import modules
+    spec = synth.SPECS["small"]
+    sd = {k: torch.from_numpy(v) for k, v in synth.clip_state_dict(spec, SEED, jitter=True).items()}
+    plsd = {k: torch.from_numpy(v) for k, v in synth.prompt_learner_state_dict(spec, 2, SEED, True).items()}
+    rng = np.random.default_rng(12)
+    for reserve in ((64, 64, 256), (1, 4, 8)):
+        e = modules.CLIPModel(sd, spec).engine(2)
+        e.load_state_dict({}, plsd)
+        e._pl_loaded = True
+        e.finalize(*reserve)
+        for trial in range(3):
+            groups, want = [], []
+            for gi in range(int(rng.integers(1, 5))):
+                n = int(rng.integers(1, 71))
+                ids = torch.from_numpy(synth.class_token_ids(n, seed=100 * trial + gi)).cuda()
+                eos = int(ids.argmax(-1).max())
+                if rng.random() < 0.5:                                   # token ids, truncated or full length
+                    sl = int(rng.choice([eos + 1, spec.context_length]))
+                    norm = int(rng.integers(0, 3))
+                    groups.append(dict(ids=ids, seq_len=sl, normalize=norm))
+                    want.append(e.encode_text_ids(ids, sl, normalize=norm))
+                else:                                                    # embedded prompts, read-out row anywhere inside the computed length
+                    sl = int(rng.integers(3, spec.context_length + 1))
+                    emb = e.embed_tokens(ids)
+                    idx = torch.from_numpy(rng.integers(0, sl, size=n).astype(np.int32)).cuda()
+                    norm = int(rng.integers(0, 3))
+                    groups.append(dict(prompts=emb, index=idx, seq_len=sl, normalize=norm))
+                    want.append(e.encode_text_embedded(emb, idx, sl, normalize=norm))
+            got = e.encode_text_groups(groups)
+            assert len(got) == len(want)
+            for a, b, g in zip(got, want, groups):
+                assert a.shape == b.shape and bool(torch.isfinite(a.float()).all())
+                assert_cosine(a.float().cpu().numpy(), b.float().cpu().numpy(), 1e-5, f"reserve {reserve}, group of {a.shape[0]} (seq_len {g['seq_len']})")
+        if reserve[1] == 4:                                              # rows beyond the workspace: per-group fallback
+            big = [torch.from_numpy(synth.class_token_ids(200, seed=900 + gi)).cuda() for gi in range(4)]
+            got = e.encode_text_groups([dict(ids=t, seq_len=spec.context_length, normalize=1) for t in big])
+            for a, t in zip(got, big):
+                assert_cosine(a.float().cpu().numpy(), e.encode_text_ids(t, spec.context_length, normalize=1).float().cpu().numpy(), 1e-5, "fallback pass")
+        del e
+    torch.cuda.empty_cache()
+
+
 def _margin_ok_rows(logits, margin):
     top2 = np.sort(logits, axis=1)[:, -2:]
     return (top2[:, 1] - top2[:, 0]) > margin
