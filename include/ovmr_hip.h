@@ -69,7 +69,8 @@ const char* ovmr_version(void);
  *   0 = the 128x128 register-staged kernel everywhere (LayerNorm-folding and fused-argmax launches still take the tile kernel).
  * "attn" (default 3): 3 = single-pass persistent kernel where the shape is its own (non-causal, 192 < L <= 208), the 32x32x16 flash
  *   kernel (= 5) for non-causal L >= 256 (ViT-L), else as 1; 5 = that kernel where it applies, else as 1;
- *   1 = flash-style LDS-DMA kernel for L >= 128, else as 0; 0 = the plain flash-style kernel.
+ *   1 = flash-style LDS-DMA kernel for L >= 128, else as 0; 0 = the plain flash-style kernel.  Every variant but 0 runs sequences of at
+ *   most 32 tokens (truncated text prompts) on the one-wave-per-(sequence, head) kernel, bit-equal to 0.
  * "ln_fold" (default 1): ln_1 / ln_2 of the fp16 towers are folded into the consuming GEMM where the shape allows
  *   (width % 256 == 0 and >= 256 token rows); 0 runs the separate LayerNorm kernel everywhere.
  * "xval_fused" (default 1): ovmr_xval_counts takes the row argmax inside the logits GEMM's epilogue (the [R, C] logits are never

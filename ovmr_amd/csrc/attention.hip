@@ -195,6 +195,7 @@ __global__ __launch_bounds__(128) void attn_f32_small(const float* __restrict__ 
 
 int launch_attention_f16_v1(const half_t* qkv, half_t* out, int B, int L, int Lq, int H, int causal, hipStream_t s);  // attention_v1.hip
 
+
 int launch_attention_f16_v3(const half_t* qkv, half_t* out, int B, int L, int Lq, int H, int causal, hipStream_t s);  // attention_v3.hip
 int launch_attention_f16_v5(const half_t* qkv, half_t* out, int B, int L, int Lq, int H, int causal, int mode, hipStream_t s);  // attention_v5.hip
 #ifdef OVMR_EXPERIMENTS
@@ -209,6 +210,11 @@ int launch_attention_f16(const half_t* qkv, half_t* out, int B, int L, int H, in
 int launch_attention_f16_q(const half_t* qkv, half_t* out, int B, int L, int Lq, int H, int causal, int variant, hipStream_t s) {
     if (B <= 0 || L <= 0 || Lq <= 0) return 0;
     if (Lq > L) return -2;
+    if (variant >= 1 && Lq == L && L <= 32) {   // short sequences (text prompts truncated to their last needed row): one wave per (sequence, head)
+        const long row0 = 0;
+        const int rc = launch_attention_f16_short(qkv, out, 1, &B, &L, &row0, H, causal, s);
+        if (rc != -100) return rc;
+    }
 #ifdef OVMR_EXPERIMENTS   // variant 4: variant 3's arithmetic with free-running producer / consumer waves (LDS flags instead of the barrier),
     // the vehicle of the r02 ablations (400 + mode: timing-only); same speed as 3, so only the experiment build carries it
     if (variant == 4 || (variant >= 400 && variant < 1000)) {

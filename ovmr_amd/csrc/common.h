@@ -161,6 +161,9 @@ int launch_fold_ln(const half_t* W, const float* gamma, const float* beta, const
                    int N, int K, hipStream_t s);
 int launch_attention_f16(const half_t* qkv, half_t* out, int B, int L, int H, int causal, int variant, hipStream_t s);
 int launch_attention_f16_q(const half_t* qkv, half_t* out, int B, int L, int Lq, int H, int causal, int variant, hipStream_t s);
+// up to 4 groups of sequences of at most 32 tokens in one launch (attention_short.hip); -100: not taken
+int launch_attention_f16_short(const half_t* qkv, half_t* out, int n_groups, const int* nseq, const int* L, const long* row0, int H,
+                               int causal, hipStream_t s);
 int launch_attention_f32(const float* qkv, float* out, int B, int L, int H, hipStream_t s);
 int launch_im2col(const void* img, int img_is_f32, half_t* out, int B, int R, int P, int Kpad, hipStream_t s);
 int launch_fill_cls(half_t* x, const half_t* cls_pos, int B, int L, int W, hipStream_t s);

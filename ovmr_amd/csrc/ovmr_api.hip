@@ -215,8 +215,18 @@ int run_block_f16(ovmr_handle* h, const Block& k, half_t* x, half_t* y, half_t* 
         CK(launch_gemm_f16(gemm(y, W, k.in_w, W, qkv, 3 * W, M, 3 * W, W, EPI_BIAS, k.in_b), h->gemm_variant, s));
     }
     if (groups) {
-        for (auto& g : *groups)
-            CK(launch_attention_f16(qkv + g.row0 * 3 * W, y + g.row0 * W, g.nseq, g.L, H, causal, h->attn_variant, s));
+        // short groups (every prompt family of a classifier head: <= ~20 tokens) share ONE launch; longer ones run group by group
+        int rc = -100;
+        if (h->attn_variant >= 1 && groups->size() <= 4) {
+            int ns[4], Ls[4];
+            long r0[4];
+            for (size_t i = 0; i < groups->size(); ++i) { ns[i] = (*groups)[i].nseq; Ls[i] = (*groups)[i].L; r0[i] = (*groups)[i].row0; }
+            rc = launch_attention_f16_short(qkv, y, (int)groups->size(), ns, Ls, r0, H, causal, s);
+            if (rc != -100) CK(rc);
+        }
+        if (rc == -100)
+            for (auto& g : *groups)
+                CK(launch_attention_f16(qkv + g.row0 * 3 * W, y + g.row0 * W, g.nseq, g.L, H, causal, h->attn_variant, s));
     } else
         CK(launch_attention_f16(qkv, y, nseq, L, H, causal, h->attn_variant, s));
     CK(launch_gemm_f16(gemm_stats(gemm(y, W, k.out_w, W, x, W, M, W, W, EPI_BIAS_RES, k.out_b, x, W), stats), h->gemm_variant, s));

@@ -234,6 +234,29 @@ def test_attention_f16(lib, variant, B, L, H, causal):
     assert float((got - ref).abs().max()) < 6e-3, f"max err {(got - ref).abs().max()}"
 
 
+@pytest.mark.parametrize("causal", [0, 1])
+@pytest.mark.parametrize("B,L,H", [(7, 1, 2), (5, 4, 8), (3, 12, 8), (2, 16, 3), (3, 17, 4), (2, 31, 12), (130, 32, 8), (1, 33, 2)])
+def test_attention_f16_short_sequences(lib, B, L, H, causal):
+    """Sequences of at most 32 tokens take the one-wave-per-(sequence, head) kernel (attention_short.hip) under every variant but 0:
+    against the fp64 statement, and bit for bit against variant 0 (the same arithmetic: one key block, exact row maximum) -- one
+    and two query tiles, a ragged last workgroup (pairs not a multiple of four), L = 33 falling back to the general kernel."""
+    g = torch.Generator().manual_seed(B * L + H + causal)
+    qkv = (torch.randn(B * L, 3 * H * 64, generator=g)).half()
+    qkv[L // 2, H * 64:H * 64 + 64] *= 6.0
+    ref = _ref_attention(qkv.float(), B, L, H, causal)
+    qd = qkv.cuda()
+    outs = {}
+    for variant in (0, 3):
+        out = torch.zeros(B * L, H * 64, dtype=torch.float16, device="cuda")
+        assert lib.ovmr_debug_attention(0, variant, _p(qd), _p(out), B, L, H, causal, _s()) == 0
+        outs[variant] = out
+    torch.cuda.synchronize()
+    got = outs[3].float().cpu()
+    assert torch.isfinite(got).all()
+    assert float((got - ref).abs().max()) < 6e-3, f"max err {(got - ref).abs().max()}"
+    assert torch.equal(outs[3], outs[0])
+
+
 @pytest.mark.parametrize("B,L,H", [(6, 18, 8), (3, 6, 2), (2, 66, 8), (1, 10, 12)])
 def test_attention_f32(lib, B, L, H):
     g = torch.Generator().manual_seed(B + L + H)
