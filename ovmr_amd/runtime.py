@@ -256,6 +256,12 @@ class Engine:
         keep, outs = [], []
         for a, g in zip(arr, groups):
             sl = int(g.get("seq_len") or self.spec.context_length)
+            # the same host-side checks as the single-family calls (only for tensors that are on the host: no device read-back here)
+            src = g.get("ids") if g.get("ids") is not None else g.get("index")
+            if isinstance(src, torch.Tensor) and not src.is_cuda and src.numel():
+                last = int(src.argmax(dim=-1).max()) if g.get("ids") is not None else int(src.max())
+                if last >= sl:
+                    raise ValueError(f"seq_len {sl} does not reach the read-out row {last} of a prompt group")
             if g.get("ids") is not None:
                 ids = self._dev(g["ids"], torch.int64)
                 keep.append(ids)
