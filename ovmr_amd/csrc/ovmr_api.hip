@@ -275,7 +275,8 @@ size_t text_groups_ws_bytes(const ovmr_handle* h, size_t M, size_t N) {
 }
 
 // Text tower (clip/model.py:824-831) over all groups in ONE pass: embedding per group, the blocks' GEMMs over all token rows,
-// causal attention per group (each with its own length -- truncation to the last needed row is exact under the causal mask),
+// causal attention with each group's own length (truncation to the last needed row is exact under the causal mask; one launch for
+// all groups of at most 32 tokens, attention_short.hip, else group by group),
 // read-out row gather, ln_final and projection per group.  The caller has checked that the rows fit the workspace.
 int run_text_groups(ovmr_handle* h, const std::vector<TextGroup>& gs, hipStream_t s) {
     const ovmr_model_desc& d = h->d;
