@@ -256,6 +256,8 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(spec, sd, pl, tok, args, n_ctx) if args.cpu_sample_classes > 0 else None   # 0: profiling runs skip the CPU leg
 
+    if sharded and dist_info is not None:
+        dist_info["collective_times_us"] = time_collectives(dist, dev, C, spec.embed_dim, n_ctx)
     if rank == 0:
         flops_img, flops_run = eng.flops_per_image(), eng.flops_per_image_executed()
         line = {
@@ -326,6 +328,45 @@ def process_group_identity(dist, dev, backend, world):
     if backend == "nccl" and info["devices_seen"] != world:
         raise RuntimeError(f"{world} ranks over RCCL sit on {info['devices_seen']} distinct device(s): {ids}")
     return info
+
+
+def time_collectives(dist, dev, C, D, n_ctx, reps=20):
+    """The two data-path collectives of the sharded job at their real payloads, timed on this process group (HIP events on the current
+    stream, median of `reps`): the all-gather of one rank's packed block [ceil(C / world), 3 D + n_ctx D + 2] fp16 and the all-reduce of
+    the int32 [3, 2, C] counters.  With one rank (--force-dist) this is what RCCL itself costs per call without any link traffic -- the
+    figure to read beside a projection (--emulate-world), not a measurement of xGMI."""
+    import torch
+    from ovmr_amd.shard import _staged
+    world = dist.get_world_size()
+    bound = -(-C // world)
+    block = torch.zeros((bound, 3 * D + n_ctx * D + 2), dtype=torch.float16, device=dev)
+    counts = torch.zeros((3, 2, C), dtype=torch.int32, device=dev)
+
+    def gather():
+        b = _staged(block, dist)
+        out = torch.empty((world * bound, b.shape[1]), dtype=torch.float16, device=b.device)
+        dist.all_gather_into_tensor(out, b)
+        return out.to(dev)
+
+    def reduce():
+        c = _staged(counts, dist)
+        dist.all_reduce(c)
+        return c.to(dev)
+
+    res = {}
+    for name, fn in (("all_gather_rows", gather), ("all_reduce_counts", reduce)):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(reps):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); fn(); e1.record()
+            torch.cuda.synchronize()
+            ts.append(e0.elapsed_time(e1) * 1000.0)
+        res[name] = round(sorted(ts)[len(ts) // 2], 1)
+    res["payload_bytes"] = {"all_gather_rows_per_rank": int(block.numel() * 2), "all_reduce_counts": int(counts.numel() * 4)}
+    return res
 
 
 class EmulatedPeers:

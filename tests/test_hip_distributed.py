@@ -82,6 +82,8 @@ def test_bench_line_proves_its_process_group(tmp_path):
     assert d["backend"] == "nccl" and d["collective_library"] == "RCCL" and d["ranks"] == 1 and d["devices_seen"] == 1
     assert len(d["device_ids"]) == 1 and d["rccl_version"] and d["rccl_version"][0].isdigit()
     assert lines["dist"]["n_gpus"] == 1 and lines["dist"]["value"] > 0
+    ct = d["collective_times_us"]                                                    # the two collectives at their real payloads, on this group
+    assert ct["all_gather_rows"] > 0 and ct["all_reduce_counts"] > 0 and ct["payload_bytes"]["all_reduce_counts"] == 3 * 2 * 12 * 4
 
 
 @pytest.mark.timeout(900)
