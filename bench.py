@@ -314,7 +314,8 @@ def process_group_identity(dist, dev, backend, world):
     import socket
     import torch
     ids = [None] * world
-    dist.all_gather_object(ids, f"{socket.gethostname()}/{device_identity(dev)}")
+    dist.all_gather_object(ids, (f"{socket.gethostname()}/{device_identity(dev)}", f"{socket.gethostname()}/index:{dev.index}"))
+    phys, index = [i[0] for i in ids], [i[1] for i in ids]
     version = None
     if backend == "nccl":
         try:
@@ -322,8 +323,13 @@ def process_group_identity(dist, dev, backend, world):
             version = ".".join(str(x) for x in v) if isinstance(v, (tuple, list)) else str(v)
         except Exception:                                  # noqa: BLE001
             version = "unknown"
+    # distinct devices by physical identity (UUID / PCI address); a runtime that reports the same identity for different devices
+    # (seen: none so far) must not kill a correctly launched job, so the per-host device INDEX is the second witness
+    seen, source = len(set(phys)), "uuid_or_pci"
+    if seen != world and len(set(index)) == world:
+        seen, source = len(set(index)), "device_index"
     info = {"backend": dist.get_backend(), "collective_library": "RCCL" if backend == "nccl" else backend, "rccl_version": version,
-            "ranks": dist.get_world_size(), "devices_seen": len(set(ids)), "device_ids": ids,
+            "ranks": dist.get_world_size(), "devices_seen": seen, "devices_seen_by": source, "device_ids": phys,
             "hip_version": getattr(torch.version, "hip", None)}
     if backend == "nccl" and info["devices_seen"] != world:
         raise RuntimeError(f"{world} ranks over RCCL sit on {info['devices_seen']} distinct device(s): {ids}")
