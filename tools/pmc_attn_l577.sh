@@ -1,5 +1,5 @@
 #!/bin/bash
-OUT=gpurun_out/r03l_pmc_attn_l577; R=$(pwd)
+OUT=${1:-gpurun_out/pmc_attn_l577}; R=$(pwd)
 mkdir -p $R/$OUT; cd /tmp; export TMPDIR=/tmp
 run() { name=$1; shift; timeout 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $R/$OUT/$name -- python3 $R/tools/attn_bench.py --only vit-l336 --reps 2 --variants 1 5 > $R/$OUT/$name.log 2>&1; }
 run sq1 SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES GRBM_GUI_ACTIVE
