@@ -43,6 +43,10 @@ PRESETS = {
     "c2": {"about": "ViT-B/16, 100 classes x 8 shots generation + 1024 queries", "set": {"classes": 100, "shots": 8, "queries": 1024, "classes_per_batch": 100}},
     "c3": {"about": "ViT-B/16 fusion inference at batch 256 against 1000 x 16-shot classifiers; value = inference images/s",
            "set": {"queries": 16384}, "value": "inference"},
+    "c4": {"about": "ViT-B/16, 64 shots, a 10 000-class vocabulary (the reference names no count: datasets/imagenet_21k_P.py), class-sharded over 8 "
+                    "ranks: ONE rank's shard (1250 classes = 80 000 exemplar images + 512 of 4096 queries) through the sharded path on this GPU, the "
+                    "other seven ranks' rows and votes recorded from their own runs; value = this rank's images/s, the 8-rank figure is a projection",
+           "set": {"classes": 10000, "shots": 64, "queries": 4096, "classes_per_batch": 1250, "emulate_world": 8, "emulate_rank": 0}, "value": "shard"},
     "c5": {"about": "ViT-L/14@336px, 1000 classes x 32 shots + 512 queries (the MFMA-bound stress configuration)",
            # 170 images x 577 tokens = 384 row tiles: 6.0 / 18.0 / 24.0 rounds of the 256 CUs on the N = 1024 / 3072 / 4096 GEMMs (r03y: 2 917 img/s
            # against 2 802 at 128 images and 128 classes per loader batch)
@@ -53,7 +57,8 @@ PRESETS = {
 DEFAULT_BATCH, DEFAULT_CLASSES_PER_BATCH = 775, 1000       # (tests/test_hip_configs.py runs the headline job with these)
 
 
-def parse():
+def parse(argv=None):
+    argv = sys.argv[1:] if argv is None else list(argv)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
@@ -103,8 +108,8 @@ def parse():
     ap.add_argument("--cpu-reps", type=int, default=3)
     ap.add_argument("--cpu-procs", type=int, default=0, help="CPU worker processes (0: usable CPUs // --cpu-threads)")
     ap.add_argument("--cpu-timeout", type=float, default=240.0, help="give up on the CPU baseline after this many seconds")
-    args = ap.parse_args()
-    given = {a.split("=")[0] for a in sys.argv[1:] if a.startswith("--")}
+    args = ap.parse_args(argv)
+    given = {a.split("=")[0] for a in argv if a.startswith("--")}
     for key, val in PRESETS[args.preset]["set"].items():          # a preset moves defaults only: explicit flags win
         if "--" + key.replace("_", "-") not in given:
             setattr(args, key, val)
@@ -149,34 +154,17 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world, timeout=to)
         dist_info = process_group_identity(dist, dev, backend, world)
 
-    spec = synth.SPECS[args.model]
+    spec, sd, pl, tok, model = make_model(args, dev, sharded)
+    eng = model.engine
     C, S, Q, n_ctx = args.classes, args.shots, args.queries, 2
     R = spec.image_resolution
 
-    # ---- synthetic CLIP-init weights, generated on the device: same shapes/std as
-    # ovmr_amd.synth, no biases/affine jitter, logit_scale = ln 100
-    gen = torch.Generator(device=dev).manual_seed(1234)
-    sd = device_clip_state(spec, gen, dev)
-    pl = device_pl_state(spec, n_ctx, gen, dev)
-    cm = modules.CLIPModel(sd, spec, str(dev))
-    cfg = modules.make_cfg(n_ctx=n_ctx, num_shots=S, eval_mode="fusion", eval_tau=10.0, output_dir="",
-                           test_batch_size=args.batch)
-    tok = torch.from_numpy(synth.class_token_ids(C, seed=4321))
-    model = modules.CustomCLIP(cfg, tok, cm, prompt_learner_state=pl,
-                               reserve=(args.batch, max(256, min(C, 2048)), max(C, 1024)), distributed=sharded,
-                               stream_text=bool(args.stream_text))
-    eng = model.engine
-    eng.set_option("gelu_exact", args.gelu_exact)
-    eng.set_option("fuse_im2col", args.fuse_im2col)
-    eng.set_option("enc_chunk", args.enc_chunk)
-    eng.set_option("last_q_cls", args.last_q_cls)
-    eng.set_option("gemm", args.gemm)
-    eng.set_option("attn", args.attn)
-    eng.set_option("ln_fold", args.ln_fold)
-
     if args.emulate_world > 1:
         assert world == 1 and not sharded, "--emulate-world runs in ONE process without a process group"
-        print(json.dumps(emulate_world(args, model, spec, dev)), flush=True)
+        if PRESETS[args.preset].get("value") == "shard":
+            print(json.dumps(shard_of_world(args, model, spec, dev)), flush=True)
+        else:
+            print(json.dumps(emulate_world(args, model, spec, dev)), flush=True)
         return
 
     # ---- this rank's shard of the job, resident in HBM (N(0,1) images, fp16), seed 1234 + rank
@@ -226,10 +214,12 @@ def main():
     for _ in range(args.steps):
         out = step()
     torch.cuda.synchronize()
+    t_own = time.perf_counter()
     if sharded:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    dt_own = (t_own - t0) / args.steps                 # this rank's own steps, before it waited for the others at the closing barrier
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
     if sharded:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -258,6 +248,15 @@ def main():
 
     if sharded and dist_info is not None:
         dist_info["collective_times_us"] = time_collectives(dist, dev, C, spec.embed_dim, n_ctx)
+        # one SCALE line shows the skew between ranks: every rank's own time per step (its steps done, before the closing barrier) and
+        # its phase split, gathered over the group itself (host objects: any backend)
+        mine = {"rank": rank, "ms_per_step_own": round(1000 * dt_own, 3), "generation_ms": round(1000 * tg, 3), "inference_ms": round(1000 * ti, 3),
+                "classes": c1 - c0, "query_images": q1 - q0}
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
+        dist_info["per_rank"] = per_rank
+        own = [p["ms_per_step_own"] for p in per_rank]
+        dist_info["rank_skew_ms"] = round(max(own) - min(own), 3)
     if rank == 0:
         flops_img, flops_run = eng.flops_per_image(), eng.flops_per_image_executed()
         line = {
@@ -294,17 +293,44 @@ def main():
 
 
 # ------------------------------------------------------------------------------------------
+def make_model(args, dev, sharded=False, output_dir=""):
+    """The job's model as bench.py times it: synthetic CLIP-init weights drawn on the device -- same shapes / std as
+    ovmr_amd.synth, no biases / affine jitter, logit_scale = ln 100 -- random class-name tokens (seed 4321), n_ctx 2, tau 10, fusion mode."""
+    import torch
+    from ovmr_amd import modules, synth
+    spec = synth.SPECS[args.model]
+    C, S, n_ctx = args.classes, args.shots, 2
+    gen = torch.Generator(device=dev).manual_seed(1234)
+    sd = device_clip_state(spec, gen, dev)
+    pl = device_pl_state(spec, n_ctx, gen, dev)
+    cm = modules.CLIPModel(sd, spec, str(dev))
+    cfg = modules.make_cfg(n_ctx=n_ctx, num_shots=S, eval_mode="fusion", eval_tau=10.0, output_dir=output_dir,
+                           test_batch_size=args.batch)
+    tok = torch.from_numpy(synth.class_token_ids(C, seed=4321))
+    model = modules.CustomCLIP(cfg, tok, cm, prompt_learner_state=pl,
+                               reserve=(args.batch, max(256, min(C, 2048)), max(C, 1024)), distributed=sharded,
+                               stream_text=bool(args.stream_text))
+    eng = model.engine
+    eng.set_option("gelu_exact", args.gelu_exact)
+    eng.set_option("fuse_im2col", args.fuse_im2col)
+    eng.set_option("enc_chunk", args.enc_chunk)
+    eng.set_option("last_q_cls", args.last_q_cls)
+    eng.set_option("gemm", args.gemm)
+    eng.set_option("attn", args.attn)
+    eng.set_option("ln_fold", args.ln_fold)
+    return spec, sd, pl, tok, model
+
+
 def device_identity(dev):
-    """A string that names the PHYSICAL device behind `dev`: its UUID where the runtime reports one, else its PCI address."""
+    """(uuid, pci) of the PHYSICAL device behind `dev`, each None where the runtime does not report it (an all-zero UUID counts as
+    not reported)."""
     import torch
     p = torch.cuda.get_device_properties(dev)
     uuid = getattr(p, "uuid", None)
-    if uuid is not None and str(uuid).strip("0-") != "":
-        return f"uuid:{uuid}"
+    uuid = f"uuid:{uuid}" if uuid is not None and str(uuid).strip("0-") != "" else None
     pci = [getattr(p, k, None) for k in ("pci_domain_id", "pci_bus_id", "pci_device_id")]
-    if all(v is not None for v in pci):
-        return "pci:%04x:%02x:%02x" % tuple(int(v) for v in pci)
-    return f"index:{dev.index}"
+    pci = "pci:%04x:%02x:%02x" % tuple(int(v) for v in pci) if all(v is not None for v in pci) else None
+    return uuid, pci
 
 
 def process_group_identity(dist, dev, backend, world):
@@ -314,8 +340,19 @@ def process_group_identity(dist, dev, backend, world):
     import socket
     import torch
     ids = [None] * world
-    dist.all_gather_object(ids, (f"{socket.gethostname()}/{device_identity(dev)}", f"{socket.gethostname()}/index:{dev.index}"))
-    phys, index = [i[0] for i in ids], [i[1] for i in ids]
+    host = socket.gethostname()
+    dist.all_gather_object(ids, (host,) + device_identity(dev) + (f"index:{dev.index}",))
+    # distinct devices by PHYSICAL identity: UUID and PCI address are two witnesses of the same fact, and two ranks that reach one
+    # physical GPU through different HIP_VISIBLE_DEVICES orderings agree on BOTH -- so the count is the larger of the two (a runtime
+    # that hands out one UUID for several boards still shows distinct PCI addresses).  The per-process device index stands in only
+    # where the runtime reports neither identity for some rank.
+    by_uuid = len({(h, u) for h, u, _, _ in ids}) if all(u for _, u, _, _ in ids) else 0
+    by_pci = len({(h, p) for h, _, p, _ in ids}) if all(p for _, _, p, _ in ids) else 0
+    if by_uuid or by_pci:
+        seen, source = max(by_uuid, by_pci), "uuid_or_pci"
+    else:
+        seen, source = len({(h, i) for h, _, _, i in ids}), "device_index"
+    phys = [f"{h}/{u or p or i}" for h, u, p, i in ids]
     version = None
     if backend == "nccl":
         try:
@@ -323,11 +360,6 @@ def process_group_identity(dist, dev, backend, world):
             version = ".".join(str(x) for x in v) if isinstance(v, (tuple, list)) else str(v)
         except Exception:                                  # noqa: BLE001
             version = "unknown"
-    # distinct devices by physical identity (UUID / PCI address); a runtime that reports the same identity for different devices
-    # (seen: none so far) must not kill a correctly launched job, so the per-host device INDEX is the second witness
-    seen, source = len(set(phys)), "uuid_or_pci"
-    if seen != world and len(set(index)) == world:
-        seen, source = len(set(index)), "device_index"
     info = {"backend": dist.get_backend(), "collective_library": "RCCL" if backend == "nccl" else backend, "rccl_version": version,
             "ranks": dist.get_world_size(), "devices_seen": seen, "devices_seen_by": source, "device_ids": phys,
             "hip_version": getattr(torch.version, "hip", None)}
@@ -521,6 +553,150 @@ def emulate_world(args, model, spec, dev):
             "config": {"workload": f"{args.model}, {C} classes x {S} shots + {Q} queries (batch {args.query_batch}), sharded over {N} emulated ranks",
                        "preset": args.preset, "encoder_reserve_images": args.batch, "classes_per_batch": args.classes_per_batch}}
     return line
+
+
+def shard_of_world(args, model, spec, dev, keep=None):
+    """BASELINE.json configuration 4 as ONE rank of `--emulate-world` ranks, for a job whose exemplar set does not fit one GPU's turn
+    (10 000 classes x 64 shots = 640 000 images = 193 GB of fp16 pixels): every rank's exemplars are drawn into ONE reusable buffer
+    (seed 1234 + rank, as the N-rank job draws them) and run through hot loop A once, untimed, to record that rank's packed classifier
+    block; the cross-validation counters of the whole job come from one pass over all C x S exemplar features against all C rows.
+    Then rank `--emulate-rank` is timed through the SHARDED code path (CustomCLIP.forward_prompt with the two collectives served from the
+    recorded blocks and votes) plus its share of the queries.  The line's value is that rank's measured images/s on this GPU;
+    `projection` holds the N-rank figure (total images / this rank's time), which excludes xGMI, barrier skew and start-up.
+    keep: a dict that receives the tensors behind the line (tests/test_hip_configs.py checks them against the oracle)."""
+    import torch
+    from ovmr_amd.data import ResidentEvalSet
+    from ovmr_amd.shard import shard_range, pack_block, local_class_bound
+    N, R0, C, S, Q, R = args.emulate_world, max(0, args.emulate_rank), args.classes, args.shots, args.queries, spec.image_resolution
+    D, n_ctx = spec.embed_dim, 2
+    eng = model.engine
+    ov = None if args.overlap < 0 else bool(args.overlap)
+    bound = local_class_bound(C, N, True, max(1, args.batch // S))
+    buf = torch.empty((bound * S, 3, R, R), dtype=torch.float16, device=dev)
+
+    def draw(r):
+        """Rank r's exemplars into the shared buffer and its queries, as the N-rank job draws them."""
+        ig = torch.Generator(device=dev).manual_seed(1234 + r)
+        c0, c1 = shard_range(C, r, N)
+        q0, q1 = shard_range(Q, r, N)
+        n = (c1 - c0) * S
+        for s in range(0, n, 1024):
+            buf[s:s + 1024][:min(1024, n - s)] = torch.randn((min(1024, n - s), 3, R, R), generator=ig, device=dev).half()
+        q = torch.randn((q1 - q0, 3, R, R), generator=ig, device=dev).half()
+        return ResidentEvalSet(buf[:n], torch.arange(c0, c1, device=dev), S, args.classes_per_batch, presharded=True), q
+
+    # ---- every rank's rows, untimed (rank R0 last: its exemplars stay in the buffer)
+    t_rec = time.perf_counter()
+    model._dist, model._text_streamed = None, True
+    with torch.no_grad():
+        model._reset_generation_state()
+        blocks = [None] * N
+        for r in [x for x in range(N) if x != R0] + [R0]:
+            loader, q = draw(r)
+            loc = model._generate_local(loader)
+            blocks[r] = pack_block(torch.cat([model.mm_classifier[loc], model.visual_classifer[loc], model._text_rows[loc],
+                                              model.visual_tokens[loc].flatten(1)], dim=1), loc, bound)
+        peer_blocks = torch.cat(blocks)
+        ref = {"mm_classifier": model.mm_classifier.clone(), "visual_classifer": model.visual_classifer.clone(),
+               "zero_shot_classifier": model._text_rows.clone(), "visual_tokens": model.visual_tokens.clone()}
+        # the whole job's votes: all C x S exemplar features against all C rows of the three classifiers (several workspace chunks)
+        ref["fusion_weight"] = model._xval_fusion_weight(torch.arange(C, device=dev), ref["mm_classifier"], ref["visual_classifer"],
+                                                         ref["zero_shot_classifier"], 10.0).clone()
+        counts_full = model.xval_counts.clone()
+        if keep is not None:
+            keep.update(ref=ref, counts_full=counts_full, eval_feat4cls=model.eval_feat4cls.clone())
+    torch.cuda.synchronize()
+    t_rec = time.perf_counter() - t_rec
+
+    if args.overlap == 1 or (args.overlap < 0 and args.query_batch <= model.OVERLAP_MAX_BATCH):
+        model._twin()
+    emu = EmulatedPeers(R0, N)
+    emu.peer_blocks = peer_blocks
+    model._dist = emu
+    c0, c1 = shard_range(C, R0, N)
+    q0, q1 = shard_range(Q, R0, N)
+
+    def queries(collect=False):
+        out, outs = None, []
+        for out in model.forward_batches((q[b:b + args.query_batch] for b in range(0, q.shape[0], args.query_batch)),
+                                         stable_inputs=True, overlap=ov):
+            if collect:
+                outs.append(out.clone())
+        return torch.cat(outs) if collect and outs else out
+
+    def step():
+        model.forward_prompt(loader)
+        return queries()
+
+    step()                                                   # records this rank's own votes (EmulatedPeers.all_reduce)
+    emu.peer_counts = counts_full - emu.local_counts
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / args.steps
+
+    # phase split and the cross-validation step alone (untimed extra passes)
+    tg = time.perf_counter(); model.forward_prompt(loader); torch.cuda.synchronize(); tg = time.perf_counter() - tg
+    ti = time.perf_counter(); out = queries(collect=True); torch.cuda.synchronize(); ti = time.perf_counter() - ti
+    own = torch.arange(c0, c1, device=dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    model._xval_fusion_weight(own, model.mm_classifier, model.visual_classifer, model.zero_shot_classifier, 10.0)
+    e1.record()
+    torch.cuda.synchronize()
+    xval_ms = e0.elapsed_time(e1)
+    h0, h1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    feats = eng.encode_image(q[:args.query_batch], normalize=True)
+    h0.record()
+    for _ in range(10):
+        eng.fused_logits(feats, model.mm_classifier, model.visual_classifer, model.zero_shot_classifier, model.fusion_weight, "fusion")
+    h1.record()
+    torch.cuda.synchronize()
+    head_us = h0.elapsed_time(h1) * 100.0
+    # the emulated rank ends with the WHOLE job's bits: every classifier row (its own recomputed, the peers' gathered), the fusion weights
+    # from the summed votes, and its query outputs finite
+    eq = {k: bool(torch.equal(getattr(model, k), ref[k])) for k in ref}
+    assert all(eq.values()), f"the sharded rank does not reproduce the whole job: {eq}"
+    assert bool(torch.isfinite(out).all()) and bool(torch.equal(model.xval_counts, counts_full))
+    n_rank = (c1 - c0) * S + (q1 - q0)
+    if keep is not None:
+        keep.update(local_counts=emu.local_counts, exemplars=buf[:(c1 - c0) * S], queries=q, out=out, classes=(c0, c1), model=model)
+    roof = measure_roofline(eng, spec, args, dev, (c1 - c0) * S, q1 - q0)
+    flops_img, flops_run = eng.flops_per_image(), eng.flops_per_image_executed()
+    value = n_rank / dt
+    xval_flops = 3 * 2.0 * (c1 - c0) * S * C * D
+    model._dist = None
+    return {
+        "metric": f"images/sec, BASELINE.json configuration {args.preset}: {PRESETS[args.preset]['about']}",
+        "value": round(value, 2), "unit": "images/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(1000 * dt, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+        "config": {"workload": f"OVMR classifier generation + fusion inference, {args.model}, {C} classes x {S} shots, rank {R0} of {N} emulated ranks: "
+                               f"{c1 - c0} classes = {(c1 - c0) * S} exemplar images (batch {args.batch}) + {q1 - q0} of {Q} query images (batch {args.query_batch}), "
+                               f"cross-validation of the local {(c1 - c0) * S} rows against all {C} classifier rows, n_ctx 2, tau 10",
+                   "parallelism": f"class/query sharding over {N} ranks; this rank alone on one GPU, the all-gather / all-reduce served from the peers' recorded blocks and votes",
+                   "preset": args.preset, "class_count_note": "the reference names no ImageNet21k-OVR class count (datasets/imagenet_21k_P.py:16-63); 10 000 chosen",
+                   "encoder_reserve_images": args.batch, "encoder_chunk_images": eng.encode_chunk, "images_per_step": n_rank},
+        "projection": {"projected": True, "emulated_world": N, "rank_timed": R0,
+                       "projected_images_per_s_all_ranks": round((C * S + Q) / dt, 1),
+                       "not_included": "RCCL all-gather / all-reduce over xGMI (device copies of recorded contributions here), barrier skew, start-up",
+                       "collective_payload_bytes": {"all_gather_rows_per_rank": int(bound * (3 * D + n_ctx * D + 2) * 2), "all_reduce_counts": int(3 * 2 * C * 4)},
+                       "peer_recording_s": round(t_rec, 1),
+                       "rank_reproduces_whole_job_bits": eq},
+        "roofline": roof,
+        "cpu_baseline": None,
+        "phases": {"generation_images_per_s": round((c1 - c0) * S / tg, 1), "generation_ms": round(1000 * tg, 2),
+                   "inference_images_per_s": round((q1 - q0) / ti, 1), "inference_ms": round(1000 * ti, 2),
+                   "xval_counts_fusion_weights_ms": round(xval_ms, 3),
+                   "xval_tflops": round(xval_flops / (xval_ms * 1e-3) / 1e12, 1),
+                   "fusion_head_us_per_query_batch": round(head_us, 1),
+                   "encoder_tflops_e2e_algorithmic": round(value * flops_img / 1e12, 1),
+                   "encoder_tflops_e2e_executed": round(value * flops_run / 1e12, 1),
+                   "e2e_frac_of_fp16_mfma_peak": round(value * flops_run / 1e12 / 2500.0, 4)},
+    }
 
 
 def device_clip_state(spec, gen, dev):

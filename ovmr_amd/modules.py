@@ -330,14 +330,11 @@ class CustomCLIP:
             image = torch.cat([im.to(device).unsqueeze(1) for im in image], dim=1).flatten(0, 1)
         return image
 
-    @torch.no_grad()
-    def forward_prompt(self, eval_set_loader: Iterable):
-        """:214-292.  Returns (mm_classifier, visual_classifer, fusion_weight) and writes
-        mm_classifiers.pt / visual_tokens.pt into cfg.OUTPUT_DIR (rank 0 only when distributed)."""
+    def _reset_generation_state(self):
+        """The buffers forward_prompt fills (:216-225): classifier rows, visual tokens, exemplar features, the per-class
+        initialised flags, and the text rows when they are produced batch by batch."""
         e, pl, dev = self.engine, self.prompt_learner, self.device
         C, S, D, n_ctx = len(self.tokenized_prompts), self.test_num_ins, e.spec.embed_dim, pl.n_ctx
-        dist = self._dist
-        rank, world = (dist.get_rank(), dist.get_world_size()) if dist else (0, 1)
         f16 = dict(dtype=torch.float16, device=dev)
         self.mm_classifier = torch.zeros((C, D), **f16)
         self.visual_classifer = torch.zeros((C, D), **f16)
@@ -348,12 +345,20 @@ class CustomCLIP:
         # (large vocabularies, or class-sharded ranks) each exemplar batch encodes the prompts of its own classes
         streamed_text = pl.zero_shot_classifier is None or getattr(self, "_text_streamed", False)
         self._text_streamed = streamed_text
-        text_clf = torch.zeros((C, D), **f16) if streamed_text else self.zero_shot_classifier
+        self._text_rows = torch.zeros((C, D), **f16) if streamed_text else self.zero_shot_classifier
+
+    def _generate_local(self, eval_set_loader: Iterable, rank: int = 0, world: int = 1) -> torch.Tensor:
+        """Hot loop A (:227-255) over the batches of `eval_set_loader` that belong to `rank` of `world`: exemplar features,
+        visual tokens, multimodal / vision (and streamed text) classifier rows written at their class labels into the buffers
+        of _reset_generation_state.  Returns the class labels this call produced, in order."""
+        e, pl, dev = self.engine, self.prompt_learner, self.device
+        S = self.test_num_ins
+        streamed_text, text_clf = self._text_streamed, self._text_rows
         local_labels = []
         presharded = bool(getattr(eval_set_loader, "presharded", False))
         cpb = max(1, self.cfg.DATALOADER.TEST.BATCH_SIZE // S)
         for batch_idx, batch in enumerate(eval_set_loader):
-            if dist and not presharded and batch["label"].shape[0] // S > cpb:
+            if world > 1 and not presharded and batch["label"].shape[0] // S > cpb:
                 # every rank iterates over every batch of a round-robin loader, so every rank raises HERE, before any of them
                 # has entered the all-gather whose block size assumes at most `cpb` classes per batch (shard.local_class_bound)
                 raise RuntimeError(f"eval-set batch {batch_idx} holds {batch['label'].shape[0] // S} classes, more than "
@@ -377,7 +382,22 @@ class CustomCLIP:
             self.inference_text_initialized[exemplar_label] = 1                     # :254
             self.visual_tokens[exemplar_label] = tokens.half()                      # :255
             local_labels.append(exemplar_label)
-        local = torch.cat(local_labels) if local_labels else torch.zeros(0, dtype=torch.long, device=dev)
+        return torch.cat(local_labels) if local_labels else torch.zeros(0, dtype=torch.long, device=dev)
+
+    @torch.no_grad()
+    def forward_prompt(self, eval_set_loader: Iterable):
+        """:214-292.  Returns (mm_classifier, visual_classifer, fusion_weight) and writes
+        mm_classifiers.pt / visual_tokens.pt into cfg.OUTPUT_DIR (rank 0 only when distributed)."""
+        e, pl, dev = self.engine, self.prompt_learner, self.device
+        C, S, D, n_ctx = len(self.tokenized_prompts), self.test_num_ins, e.spec.embed_dim, pl.n_ctx
+        dist = self._dist
+        rank, world = (dist.get_rank(), dist.get_world_size()) if dist else (0, 1)
+        f16 = dict(dtype=torch.float16, device=dev)
+        self._reset_generation_state()
+        presharded = bool(getattr(eval_set_loader, "presharded", False))
+        cpb = max(1, self.cfg.DATALOADER.TEST.BATCH_SIZE // S)
+        local = self._generate_local(eval_set_loader, rank, world)
+        streamed_text, text_clf = self._text_streamed, self._text_rows
 
         if dist:
             # ONE all-gather (RCCL) of the packed classifier rows (SURVEY.md 8e): [mm | v | text | tokens | label bits]

@@ -50,8 +50,15 @@ def main():
     q = torch.from_numpy(synth.images(5, spec.image_resolution, 777))
     out = model(q, eval_set_loader=loader)
     torch.cuda.synchronize()
+    devices_seen, rccl_version = None, None
+    if dist.is_initialized():
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        import bench
+        info = bench.process_group_identity(dist, model.device, backend, world)      # raises on every rank when RCCL ranks share a device
+        devices_seen, rccl_version = info["devices_seen"], info["rccl_version"]
     if rank == 0:
-        torch.save({"out": out.cpu(), "mm": model.mm_classifier.cpu(), "v": model.visual_classifer.cpu(),
+        torch.save({"devices_seen": devices_seen, "rccl_version": rccl_version, "world": world,
+                    "out": out.cpu(), "mm": model.mm_classifier.cpu(), "v": model.visual_classifer.cpu(),
                     "t": model.zero_shot_classifier.cpu(), "w": model.fusion_weight.cpu(), "counts": model.xval_counts.cpu(),
                     "tokens": model.visual_tokens.cpu(), "files": sorted(os.listdir(out_dir)),
                     "backend": dist.get_backend() if dist.is_initialized() else "none",

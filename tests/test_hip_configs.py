@@ -197,6 +197,103 @@ def test_config_c4_six_thousand_classes_single_process(O, tmp_path):
     assert_cosine(out.numpy(), ref.numpy(), COS_TOL, "fused rows at C = 6000")
 
 
+@pytest.mark.timeout(3000)
+def test_config_c4_vitb16_sixty_four_shots_one_rank_of_eight(O):
+    """BASELINE.json configuration 4 on its own architecture: ViT-B/16, 64 shots (aggregator sequence 66 behind the real image
+    tower), a 5040-class vocabulary (>= 5000: the reference leaves zero_shot_classifier = None at
+    trainers/mm_classifier_one_prompt.py:118 and fails at :263-265), class-sharded over 8 ranks -- the job `bench.py --preset c4`
+    runs (bench.shard_of_world), at 5040 instead of 10 000 classes: all 8 ranks' exemplars (322 560 images, 630 classes each) go
+    through hot loop A, rank 0 then runs the SHARDED path with the peers' recorded rows and votes.  Checked:
+      * rank 0 ends with the whole job's bits (rows, tokens, counters, fusion weights) -- asserted inside shard_of_world;
+      * 3 sampled classes (2 of rank 0, 1 of rank 5): features, mm / vision / text rows, visual tokens against the oracle;
+      * ALL 3 x 2 x 5040 counters of the whole job AND rank 0's own votes against the CPU restatement's bounds, 8 064 rows at a time
+        (an argmax may land on any class within 2 fp16 steps of the row maximum);
+      * fusion weights = softmax(tau * F1(counters)) exactly;
+      * the four EVAL_MODEs on 8 queries against the oracle (oracle features, the job's classifiers and weights)."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    from ovmr_amd.shard import shard_range
+    dev = torch.device("cuda:0")
+    C, S, N = 5040, 64, 8
+    args = bench.parse(["--preset", "c4", "--classes", str(C), "--classes-per-batch", str(C // N), "--queries", "2048",
+                        "--steps", "1", "--warmup", "0", "--no-cpu-baseline"])
+    assert args.shots == S and args.emulate_world == N and args.model == "ViT-B/16"
+    spec, sd, pl, tok, model = bench.make_model(args, dev)
+    assert model.zero_shot_classifier is None or model._text_streamed
+    keep = {}
+    line = bench.shard_of_world(args, model, spec, dev, keep)
+    assert line["projection"]["projected"] and all(line["projection"]["rank_reproduces_whole_job_bits"].values())
+    assert line["config"]["images_per_step"] == (C // N) * S + 2048 // N and line["value"] > 0
+    ref, counts_full, feats = keep["ref"], keep["counts_full"].cpu().numpy(), keep["eval_feat4cls"]
+    mm, v, t, fw = ref["mm_classifier"], ref["visual_classifer"], ref["zero_shot_classifier"], ref["fusion_weight"]
+    assert mm.shape == (C, 512) and fw.shape == (C, 3)
+    assert bool(torch.isfinite(mm.float()).all() and torch.isfinite(v.float()).all() and torch.isfinite(t.float()).all() and torch.isfinite(fw).all())
+
+    # ---- sampled classes against the oracle: two of rank 0 (its exemplars are still resident), the first class of rank 5 (redrawn)
+    cpu_sd = O.convert_weights({k: x.detach().float().cpu() for k, x in sd.items()}, "fp16")
+    cpu_pl = {k: x.detach().float().cpu() for k, x in pl.items()}
+    R = spec.image_resolution
+    ex0 = keep["exemplars"]
+    c5 = shard_range(C, 5, N)[0]
+    ig = torch.Generator(device=dev).manual_seed(1234 + 5)
+    first = torch.randn((1024, 3, R, R), generator=ig, device=dev).half()
+    sample = [0, 629, c5]
+    rows = torch.cat([ex0[0:S], ex0[629 * S:630 * S], first[:S]]).cpu()
+    torch.set_num_threads(min(32, os.cpu_count()))
+    with torch.no_grad():
+        r = O.forward_prompt(rows, torch.arange(3).repeat_interleave(S), tok[sample], cpu_sd, cpu_pl, 2, 10.0, 3, "fp16")
+        qf = O.l2_normalize(O.encode_image(keep["queries"][:8].cpu(), cpu_sd))
+    assert_cosine(feats[sample].flatten(0, 1).float().cpu().numpy(), r["eval_feat4cls"].flatten(0, 1).float().numpy(), COS_TOL, "eval_feat4cls")
+    assert_cosine(mm[sample].float().cpu().numpy(), r["mm_classifier"].numpy(), COS_TOL, "mm rows")
+    assert_cosine(v[sample].float().cpu().numpy(), r["vision_classifier"].numpy(), COS_TOL, "vision rows")
+    assert_cosine(t[sample].float().cpu().numpy(), r["text_classifier"].numpy(), COS_TOL, "text rows")
+    assert_cosine(ref["visual_tokens"][sample].float().cpu().numpy(), r["visual_tokens"].float().numpy(), COS_TOL, "visual tokens")
+
+    # ---- every counter, whole job and rank 0's own votes, in row chunks (the bounds add up over rows)
+    f_cpu = feats.flatten(0, 1).cpu()
+    ls = float(model.engine.logit_scale)
+    local_counts = keep["local_counts"].cpu().numpy()
+    n_local = (C // N) * S
+    chunk = 8064                                                                  # 126 classes: rank boundaries fall on chunk boundaries
+    assert n_local % chunk == 0
+    for m, clf in enumerate((mm, v, t)):
+        clf_cpu = clf.cpu()
+        acc = np.zeros((4, C), dtype=np.int64)
+        for r0 in range(0, C * S, chunk):
+            lg = _fp16_logits(f_cpu[r0:r0 + chunk], clf_cpu, ls)
+            row_lab = np.repeat(np.arange(r0 // S, (r0 + chunk) // S), S)
+            acc += np.stack(_count_bounds(lg, row_lab, C, 0.13))
+            if r0 + chunk == n_local:
+                tp_lo, tp_hi, n_lo, n_hi = acc
+                assert local_counts[m, 1].sum() == n_local
+                assert ((local_counts[m, 0] >= tp_lo) & (local_counts[m, 0] <= tp_hi)).all(), f"rank 0 tp of classifier {m}"
+                assert ((local_counts[m, 1] >= n_lo) & (local_counts[m, 1] <= n_hi)).all(), f"rank 0 n_pred of classifier {m}"
+        tp_lo, tp_hi, n_lo, n_hi = acc
+        assert counts_full[m, 1].sum() == C * S
+        assert ((counts_full[m, 0] >= tp_lo) & (counts_full[m, 0] <= tp_hi)).all(), f"tp of classifier {m}"
+        assert ((counts_full[m, 1] >= n_lo) & (counts_full[m, 1] <= n_hi)).all(), f"n_pred of classifier {m}"
+    f1 = torch.stack([O.f1_from_counts(torch.from_numpy(counts_full[m, 0]), torch.from_numpy(counts_full[m, 1]), torch.full((C,), S))
+                      for m in range(3)], -1)
+    np.testing.assert_allclose(fw.cpu().numpy(), (10.0 * f1).softmax(-1).numpy(), atol=1e-6)
+
+    # ---- the four EVAL_MODEs on 8 queries
+    q8 = keep["queries"][:8]
+    m = keep["model"]
+    want = O.inference_logits(qf, mm.cpu(), v.cpu(), t.cpu(), fw.cpu(), torch.tensor(ls), "fusion")
+    assert_cosine(keep["out"][:8].cpu().numpy(), want.numpy(), COS_TOL, "fusion rows of the timed query loop (batch 256, two in flight)")
+    for mode in ("fusion", "text", "vision", "multimodal"):
+        m.cfg.EVAL_MODE = mode
+        out = m(q8).cpu()
+        want = O.inference_logits(qf, mm.cpu(), v.cpu(), t.cpu(), fw.cpu(), torch.tensor(ls), mode)
+        assert out.shape == (8, C)
+        assert_cosine(out.numpy(), want.numpy(), COS_TOL, f"{mode} rows at C = {C}")
+    m.cfg.EVAL_MODE = "fusion"
+    print(f"c4 at ViT-B/16: rank 0 of {N}: {line['value']:.0f} img/s, generation {line['phases']['generation_images_per_s']:.0f} img/s, "
+          f"xval {line['phases']['xval_counts_fusion_weights_ms']:.2f} ms")
+    del keep, model, m
+    torch.cuda.empty_cache()
+
+
 def test_config_c5_head_at_width_768(O, tmp_path):
     """embed_dim = transformer_width = 768 (the ViT-L/14 head: 12 text heads, fp32 aggregator 768 wide with 12 heads,
     prompts assembled at width 768, cross-validation / fused logits at K = 768) on a 2-layer model: generation and the

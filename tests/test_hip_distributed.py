@@ -62,6 +62,28 @@ def test_rccl_collectives_with_one_rank_bit_equal(tmp_path):
         assert got["files"] == ["mm_classifiers.pt", "visual_tokens.pt"]
 
 
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs at least 2 GPUs: one RCCL rank per device (armed for the 8-GPU node)")
+@pytest.mark.timeout(1500)
+def test_rccl_one_rank_per_device_bit_equal_to_single_process(tmp_path):
+    """N > 1 over RCCL, one process per GPU (world = min(8, devices)): the class-sharded job -- packed all-gather and counter
+    all-reduce on device tensors through librccl over xGMI -- must leave classifier rows, visual tokens, counters, fusion weights
+    and fused outputs BIT-EQUAL to the one-process run, for the round-robin and for the class-sharded loader; every rank sits on a
+    device of its own (bench.process_group_identity: devices_seen == world, checked by physical identity) and the RCCL version
+    is on record.  Skipped on a one-GPU box (collected there, so the day more devices exist it runs by itself)."""
+    world = min(8, torch.cuda.device_count())
+    C = 2 * world + 3                                                 # ragged over the ranks
+    single = _launch(1, str(tmp_path / "w1.pt"), 0, C)
+    assert single["backend"] == "none" and not single["sharded_path"]
+    for presharded in (0, 1):
+        got = _launch(world, str(tmp_path / f"rccl_w{world}_{presharded}.pt"), presharded, C, backend="nccl")
+        assert got["backend"] == "nccl" and got["sharded_path"] and got["rccl_loaded"]
+        assert got["world"] == world and got["devices_seen"] == world
+        assert got["rccl_version"] and got["rccl_version"][0].isdigit()
+        for k in ("mm", "v", "t", "tokens", "counts", "w", "out"):
+            assert torch.equal(single[k], got[k]), f"nccl world {world}, presharded {presharded}: {k} differs"
+        assert got["files"] == ["mm_classifiers.pt", "visual_tokens.pt"]
+
+
 @pytest.mark.timeout(900)
 def test_bench_line_proves_its_process_group(tmp_path):
     """A SCALE record must say what it ran on: `bench.py --force-dist` (one rank, process group nccl = RCCL on cuda:0, the sharded
