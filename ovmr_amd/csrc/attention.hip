@@ -238,7 +238,7 @@ int launch_attention_f16_q(const half_t* qkv, half_t* out, int B, int L, int Lq,
         if (rc != -100) return rc;
         variant = 1;
     }
-    if (variant >= 50 && variant < 60) {   // variant 5's scheduling experiments (50 + mode)
+    if (variant >= 50 && variant < 306) {   // variant 5's scheduling experiments (50 + mode; 66 = the folded exponent)
         const int rc = launch_attention_f16_v5(qkv, out, B, L, Lq, H, causal, variant - 50, s);
         if (rc != -100) return rc;
         variant = 1;

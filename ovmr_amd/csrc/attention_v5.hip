@@ -75,9 +75,17 @@ __device__ long long g_attn5_stamps[4 * 256];
 // <2, MFMA> 146 / 275 / 170.  <2, false> is what the launcher runs.
 // NW: waves (32-row query tiles) per workgroup, 3 or 4: the launcher takes the one that wastes fewer wave slots (L = 257: 9 tiles = 3 x 3).
 // SCH (experiment build): 1 = the two score chains interleaved, 2 = the next block's DMA issued behind the score MFMAs.
-template <int STAGES5, bool RS_MFMA, int NW, int SCH>
-__global__ __launch_bounds__(NW * 64, STAGES5 == 3 ? 3 : 4) void attn_f16_v5(const half_t* __restrict__ qkv, half_t* __restrict__ out,
+// FOLD: the exponent's multiply-add folded into the score product itself.  Q is scaled by scale * log2(e) once per tile (fp16: one more
+// rounding of 2^-11 per element, below the reference's own rounding of every score to fp16, clip/model.py:184-188 through
+// nn.MultiheadAttention), and the C operand of the first score MFMA is a 16-register tile holding -m_run in every register (a lane's
+// 16 scores belong to ONE query), so the matrix pipe hands back t - m_run and the exponential reads it directly: 32 v_fma_f32 per
+// 64-key block and wave less (attention table).  The reference m_run starts at the first block's row maximum exactly as
+// before; the rare rescale (a row maximum more than 8 above the reference) also re-bases the live scores and rewrites the tile.
+// OCC: waves per SIMD the register budget is set for (4: 128 registers; FOLD needs ~140, so its tile costs the fourth wave or spills).
+template <int STAGES5, bool RS_MFMA, int NW, int SCH, bool FOLD = false, int OCC = (STAGES5 == 3 ? 3 : 4), bool HALF = false, int PRIO = 0>
+__global__ __launch_bounds__(NW * 64, OCC) void attn_f16_v5(const half_t* __restrict__ qkv, half_t* __restrict__ out,
                                                                            int L, int Lq, int H, int nT, int nWG, int nBH, float scale_log2e) {
+    static_assert(!HALF || !RS_MFMA, "the half-block body keeps its row sums on the vector ALU");
     static_assert(STAGES5 == 2 || NW == 4, "the counted wait of the three-stage ring assumes four DMA instructions per wave");
     __shared__ __attribute__((aligned(16))) half_t smem[STAGES5 * STAGE5];
 
@@ -102,6 +110,12 @@ __global__ __launch_bounds__(NW * 64, STAGES5 == 3 ? 3 : 4) void attn_f16_v5(con
         const int qc = min(q, L - 1);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const half8_t*)(base + (long)qc * ld + ks * 16 + h * 8);
+        if (FOLD) {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) qf[ks][j] = (half_t)((float)qf[ks][j] * scale_log2e);
+        }
     }
 
     // staging: 16 LDS-DMA instructions of 8 rows x 128 B per block (8 of K rows, then 8 of V rows), dealt round-robin to the waves.  The
@@ -136,7 +150,13 @@ __global__ __launch_bounds__(NW * 64, STAGES5 == 3 ? 3 : 4) void attn_f16_v5(con
         }
     };
 
-    float m_run = -INFINITY;                               // reference maximum of the exponentials (scaled domain), variant 1's lazy form
+    float m_run = FOLD ? 0.f : -INFINITY;                  // reference maximum of the exponentials (scaled domain), variant 1's lazy form
+    [[maybe_unused]] float thr = -INFINITY, dfloor = -INFINITY;   // FOLD: rescale threshold and lower bound of the reference shift (first block: none)
+    float16_t cm;                                          // FOLD: -m_run in every register: the C operand of the first score MFMA of a chain
+    if (FOLD) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) cm[k] = 0.f;
+    }
     float16_t o[2];
 #pragma unroll
     for (int k = 0; k < 16; ++k) { o[0][k] = 0.f; o[1][k] = 0.f; }
@@ -195,14 +215,92 @@ __global__ __launch_bounds__(NW * 64, STAGES5 == 3 ? 3 : 4) void attn_f16_v5(con
         float16_t zero16;
 #pragma unroll
         for (int k = 0; k < 16; ++k) zero16[k] = 0.f;      // (folds into the MFMA's inline constant 0: no accumulator zeroing)
+        if constexpr (HALF) {
+            // One 32-key score tile at a time: 4 score MFMAs, the row maximum of ITS 16 registers, the (lazy) reference check, 16
+            // exponentials, two PV steps -- then the second half.  Only one score tile is live (16 registers less), which is what lets
+            // FOLD's -m_run tile in without costing the fourth wave per SIMD; the rescale decision is taken per 32 keys.
+#pragma unroll
+            for (int sb = 0; sb < 2; ++sb) {
+                float16_t sc;
+                if (FOLD) __builtin_amdgcn_sched_barrier(0);      // (the second half's score tile must not be hoisted over the first half's softmax: registers)
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const half8_t kf = *(const half8_t*)(smem + koff[ks] + (st_off + sb * 32 * 64));
+                    sc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], ks == 0 ? (FOLD ? cm : zero16) : sc, 0, 0, 0);
+                }
+                if (nvalid < KB5) {
+                    const int thr_k = nvalid - sb * 32 - 4 * h;
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) sc[k] = ((k & 3) + 8 * (k >> 2) < thr_k) ? sc[k] : -INFINITY;
+                }
+                float mx = sc[0];
+#pragma unroll
+                for (int k = 1; k < 16; ++k) mx = fmaxf(mx, sc[k]);
+                {
+                    const unsigned u = __builtin_bit_cast(unsigned, mx);
+                    auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+                    mx = fmaxf(__builtin_bit_cast(float, (unsigned)sw[0]), __builtin_bit_cast(float, (unsigned)sw[1]));
+                }
+                float m_ref;
+                if constexpr (FOLD) {
+                    if (__builtin_amdgcn_ballot_w64(mx > thr) != 0) {
+                        const float delta = fmaxf(mx, dfloor);
+                        const float alpha = fminf(__builtin_amdgcn_exp2f(-delta), 3.0e38f);
+                        m_run += delta;
+#pragma unroll
+                        for (int k = 0; k < 16; ++k) { o[0][k] *= alpha; o[1][k] *= alpha; }
+                        lsum *= alpha;
+#pragma unroll
+                        for (int k = 0; k < 16; ++k) { sc[k] -= delta; cm[k] = -m_run; }
+                    }
+                    thr = 8.0f;
+                    dfloor = 0.f;
+                    m_ref = 0.f;
+                } else {
+                    const float mxs = mx * scale_log2e;
+                    if (__builtin_amdgcn_ballot_w64(mxs > m_run + 8.0f) != 0) {
+                        const float m_new = fmaxf(m_run, mxs);
+                        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+                        m_run = m_new;
+#pragma unroll
+                        for (int k = 0; k < 16; ++k) { o[0][k] *= alpha; o[1][k] *= alpha; }
+                        lsum *= alpha;
+                    }
+                    m_ref = m_run;
+                }
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const int st = sb * 2 + t;
+                    half8_t pf;
+#pragma unroll
+                    for (int j = 0; j < 8; j += 2) {
+                        const float2_t e2 = {FOLD ? __builtin_amdgcn_exp2f(sc[8 * t + j]) : __builtin_amdgcn_exp2f(__builtin_fmaf(sc[8 * t + j], scale_log2e, -m_ref)),
+                                             FOLD ? __builtin_amdgcn_exp2f(sc[8 * t + j + 1]) : __builtin_amdgcn_exp2f(__builtin_fmaf(sc[8 * t + j + 1], scale_log2e, -m_ref))};
+                        lsum += e2[0] + e2[1];
+                        const half2_t p2 = __builtin_convertvector(e2, half2_t);
+                        pf[j] = p2[0];
+                        pf[j + 1] = p2[1];
+                    }
+#pragma unroll
+                    for (int blk = 0; blk < 2; ++blk) {
+                        const half4_t v0 = tr_read5(smem + voff[blk] + (st_off + st * 16 * 64));
+                        const half4_t v1 = tr_read5(smem + voff[blk] + (st_off + (st * 16 + 8) * 64));
+                        const half8_t vf = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                        o[blk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, o[blk], 0, 0, 0);
+                    }
+                }
+            }
+            return;
+        }
         float16_t s[2];
+        if (PRIO & 1) __builtin_amdgcn_s_setprio(1);       // PRIO 1: the score chain issues ahead of the other waves' softmax; 2: the PV phase too
         if (SCH & 1) {
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
 #pragma unroll
                 for (int sb = 0; sb < 2; ++sb) {
                     const half8_t kf = *(const half8_t*)(smem + koff[ks] + (st_off + sb * 32 * 64));
-                    s[sb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], ks == 0 ? zero16 : s[sb], 0, 0, 0);
+                    s[sb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], ks == 0 ? (FOLD ? cm : zero16) : s[sb], 0, 0, 0);
                 }
             }
         } else {
@@ -211,7 +309,7 @@ __global__ __launch_bounds__(NW * 64, STAGES5 == 3 ? 3 : 4) void attn_f16_v5(con
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) {
                     const half8_t kf = *(const half8_t*)(smem + koff[ks] + (st_off + sb * 32 * 64));
-                    s[sb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], ks == 0 ? zero16 : s[sb], 0, 0, 0);
+                    s[sb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], ks == 0 ? (FOLD ? cm : zero16) : s[sb], 0, 0, 0);
                 }
             }
         }
@@ -220,6 +318,7 @@ __global__ __launch_bounds__(NW * 64, STAGES5 == 3 ? 3 : 4) void attn_f16_v5(con
             if (more) stage((ST + STAGES5 - 1) % STAGES5, kb + STAGES5 - 1);
             __builtin_amdgcn_sched_barrier(0);
         }
+        if (PRIO == 1) __builtin_amdgcn_s_setprio(0);
         A5_STAMP()                                         // 3: score MFMAs issued
         // register k of a score tile holds key (k & 3) + 8 (k >> 2) + 4 h of its 32-key half
         if (nvalid < KB5) {                                // (wave-uniform) the last block: keys >= L get -inf, i.e. p = 0
@@ -240,8 +339,30 @@ __global__ __launch_bounds__(NW * 64, STAGES5 == 3 ? 3 : 4) void attn_f16_v5(con
             auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);
             mx = fmaxf(__builtin_bit_cast(float, (unsigned)sw[0]), __builtin_bit_cast(float, (unsigned)sw[1]));
         }
-        const float mxs = mx * scale_log2e;
         A5_STAMP()                                         // 4: row maxima (the scores are back)
+        float m_ref;
+        if constexpr (FOLD) {
+            // the scores arrive as t - m_run: a row needs a new reference when its block maximum exceeds 8; the first block sets the
+            // reference to its row maximum whatever its sign (so that every row keeps an exponential equal to 1)
+            // (thr / dfloor: -inf in the first block, 8 / 0 afterwards -- wave-uniform values instead of a second copy of the block body)
+            if (__builtin_amdgcn_ballot_w64(mx > thr) != 0) {
+                const float delta = fmaxf(mx, dfloor);
+                const float alpha = fminf(__builtin_amdgcn_exp2f(-delta), 3.0e38f);   // (first block: o = 0 and exp2(-delta) may overflow: 0 * finite)
+                m_run += delta;
+#pragma unroll
+                for (int k = 0; k < 16; ++k) { o[0][k] *= alpha; o[1][k] *= alpha; }
+                if (RS_MFMA) {
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) ol[k] *= alpha;
+                } else lsum *= alpha;
+#pragma unroll
+                for (int k = 0; k < 16; ++k) { s[0][k] -= delta; s[1][k] -= delta; cm[k] = -m_run; }
+            }
+            thr = 8.0f;
+            dfloor = 0.f;
+            m_ref = 0.f;
+        } else {
+        const float mxs = mx * scale_log2e;
         if (__builtin_amdgcn_ballot_w64(mxs > m_run + 8.0f) != 0) {      // wave-uniform: some row needs a new reference
             const float m_new = fmaxf(m_run, mxs);
             const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);   // <= 0 (first block: -inf -> 0)
@@ -253,15 +374,18 @@ __global__ __launch_bounds__(NW * 64, STAGES5 == 3 ? 3 : 4) void attn_f16_v5(con
                 for (int k = 0; k < 16; ++k) ol[k] *= alpha;
             } else lsum *= alpha;
         }
-        const float m_ref = m_run;
+        m_ref = m_run;
+        }
         A5_STAMP()                                         // 5: reference settled
 #pragma unroll
         for (int st = 0; st < 4; ++st) {                   // 16-key PV steps: registers 8 t .. 8 t + 7 of half sb = st >> 1, t = st & 1
             half8_t pf;
 #pragma unroll
             for (int j = 0; j < 8; j += 2) {               // pairs: v_cvt_pk_f16_f32 (element-wise casts came out as quarter-rate v_fma_mixlo_f16)
-                const float2_t e2 = {__builtin_amdgcn_exp2f(__builtin_fmaf(s[st >> 1][8 * (st & 1) + j], scale_log2e, -m_ref)),
-                                     __builtin_amdgcn_exp2f(__builtin_fmaf(s[st >> 1][8 * (st & 1) + j + 1], scale_log2e, -m_ref))};
+                const float2_t e2 = {FOLD ? __builtin_amdgcn_exp2f(s[st >> 1][8 * (st & 1) + j])
+                                          : __builtin_amdgcn_exp2f(__builtin_fmaf(s[st >> 1][8 * (st & 1) + j], scale_log2e, -m_ref)),
+                                     FOLD ? __builtin_amdgcn_exp2f(s[st >> 1][8 * (st & 1) + j + 1])
+                                          : __builtin_amdgcn_exp2f(__builtin_fmaf(s[st >> 1][8 * (st & 1) + j + 1], scale_log2e, -m_ref))};
                 if (!RS_MFMA) lsum += e2[0] + e2[1];
                 const half2_t p2 = __builtin_convertvector(e2, half2_t);
                 pf[j] = p2[0];
@@ -277,6 +401,7 @@ __global__ __launch_bounds__(NW * 64, STAGES5 == 3 ? 3 : 4) void attn_f16_v5(con
             if (RS_MFMA) ol = __builtin_amdgcn_mfma_f32_32x32x16_f16(ones, pf, ol, 0, 0, 0);
             if (st == 1) { A5_STAMP() }                    // 6: half of the PV steps issued
         }
+        if (PRIO & 2) __builtin_amdgcn_s_setprio(0);
         A5_STAMP()                                         // 7: block end
     };
     // A last block of at most 16 keys -- every CLIP ViT has one: L = G*G + 1 leaves ONE key behind the last full block -- is peeled
@@ -303,7 +428,7 @@ __global__ __launch_bounds__(NW * 64, STAGES5 == 3 ? 3 : 4) void attn_f16_v5(con
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 const half8_t kf = *(const half8_t*)(smem + koff[ks] + st_off);
-                s0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], ks == 0 ? zero16 : s0, 0, 0, 0);
+                s0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], ks == 0 ? (FOLD ? cm : zero16) : s0, 0, 0, 0);
             }
             const int thr = tail - 4 * h;                  // registers 0..7: keys (k & 3) + 8 (k >> 2) + 4 h
             float mx = -INFINITY;
@@ -317,6 +442,23 @@ __global__ __launch_bounds__(NW * 64, STAGES5 == 3 ? 3 : 4) void attn_f16_v5(con
                 auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);
                 mx = fmaxf(__builtin_bit_cast(float, (unsigned)sw[0]), __builtin_bit_cast(float, (unsigned)sw[1]));
             }
+            float m_ref;
+            if constexpr (FOLD) {
+                if (__builtin_amdgcn_ballot_w64(mx > thr) != 0) {
+                    const float delta = fmaxf(mx, dfloor);
+                    const float alpha = fminf(__builtin_amdgcn_exp2f(-delta), 3.0e38f);
+                    m_run += delta;
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) { o[0][k] *= alpha; o[1][k] *= alpha; }
+                    if (RS_MFMA) {
+#pragma unroll
+                        for (int k = 0; k < 16; ++k) ol[k] *= alpha;
+                    } else lsum *= alpha;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) s0[k] -= delta;
+                }
+                m_ref = 0.f;
+            } else {
             const float mxs = mx * scale_log2e;
             if (__builtin_amdgcn_ballot_w64(mxs > m_run + 8.0f) != 0) {
                 const float m_new = fmaxf(m_run, mxs);
@@ -329,12 +471,13 @@ __global__ __launch_bounds__(NW * 64, STAGES5 == 3 ? 3 : 4) void attn_f16_v5(con
                     for (int k = 0; k < 16; ++k) ol[k] *= alpha;
                 } else lsum *= alpha;
             }
-            const float m_ref = m_run;
+            m_ref = m_run;
+            }
             half8_t pf;
 #pragma unroll
             for (int j = 0; j < 8; j += 2) {
-                const float2_t e2 = {__builtin_amdgcn_exp2f(__builtin_fmaf(s0[j], scale_log2e, -m_ref)),
-                                     __builtin_amdgcn_exp2f(__builtin_fmaf(s0[j + 1], scale_log2e, -m_ref))};
+                const float2_t e2 = {FOLD ? __builtin_amdgcn_exp2f(s0[j]) : __builtin_amdgcn_exp2f(__builtin_fmaf(s0[j], scale_log2e, -m_ref)),
+                                     FOLD ? __builtin_amdgcn_exp2f(s0[j + 1]) : __builtin_amdgcn_exp2f(__builtin_fmaf(s0[j + 1], scale_log2e, -m_ref))};
                 if (!RS_MFMA) lsum += e2[0] + e2[1];
                 const half2_t p2 = __builtin_convertvector(e2, half2_t);
                 pf[j] = p2[0];
@@ -388,12 +531,12 @@ __global__ __launch_bounds__(NW * 64, STAGES5 == 3 ? 3 : 4) void attn_f16_v5(con
 }  // namespace
 
 namespace {
-template <int NW, int SCH>
+template <int NW, int SCH, bool FOLD = false, int STAGES = 2, int OCC = 4, bool HALF = false, int PRIO = 0>
 int launch_v5(const half_t* qkv, half_t* out, int B, int L, int Lq, int H, hipStream_t s) {
     const int nT = (Lq + 31) / 32, nWG = (nT + NW - 1) / NW, nBH = B * H;
     const float sl2e = 0.125f * 1.4426950408889634f;
     const dim3 grid((unsigned)((long)((nBH + 7) / 8) * 8 * nWG));
-    hipLaunchKernelGGL((attn_f16_v5<2, false, NW, SCH>), grid, dim3(NW * 64), 0, s, qkv, out, L, Lq, H, nT, nWG, nBH, sl2e);
+    hipLaunchKernelGGL((attn_f16_v5<STAGES, false, NW, SCH, FOLD, OCC, HALF, PRIO>), grid, dim3(NW * 64), 0, s, qkv, out, L, Lq, H, nT, nWG, nBH, sl2e);
     return (int)hipGetLastError();
 }
 }  // namespace
@@ -405,6 +548,15 @@ int launch_attention_f16_v5(const half_t* qkv, half_t* out, int B, int L, int Lq
     const int nT = (Lq + 31) / 32;
     const bool three = ((nT + 2) / 3) * 3 < ((nT + 3) / 4) * 4 && !(mode & 4);      // fewer idle wave slots with 3-wave workgroups
 #ifdef OVMR_EXPERIMENTS
+    if (mode & 128) return (mode & 1) ? (three ? launch_v5<3, 0, false, 2, 4, false, 3>(qkv, out, B, L, Lq, H, s) : launch_v5<4, 0, false, 2, 4, false, 3>(qkv, out, B, L, Lq, H, s))
+                                      : (three ? launch_v5<3, 0, false, 2, 4, false, 1>(qkv, out, B, L, Lq, H, s) : launch_v5<4, 0, false, 2, 4, false, 1>(qkv, out, B, L, Lq, H, s));
+    if (mode & 64) return (mode & 16) ? (three ? launch_v5<3, 0, true, 2, 4, true>(qkv, out, B, L, Lq, H, s) : launch_v5<4, 0, true, 2, 4, true>(qkv, out, B, L, Lq, H, s))
+                                      : (three ? launch_v5<3, 0, false, 2, 4, true>(qkv, out, B, L, Lq, H, s) : launch_v5<4, 0, false, 2, 4, true>(qkv, out, B, L, Lq, H, s));
+    if ((mode & 48) == 48) return (mode & 1) ? launch_v5<4, 0, true, 3, 3>(qkv, out, B, L, Lq, H, s)                               // folded, 3 waves / SIMD: 3-stage ring (4-wave workgroups)
+                                             : (three ? launch_v5<3, 0, true, 2, 3>(qkv, out, B, L, Lq, H, s) : launch_v5<4, 0, true, 2, 3>(qkv, out, B, L, Lq, H, s));
+    if ((mode & 16) && (mode & 3) == 1) return three ? launch_v5<3, 1, true>(qkv, out, B, L, Lq, H, s) : launch_v5<4, 1, true>(qkv, out, B, L, Lq, H, s);
+    if ((mode & 16) && (mode & 3) == 3) return three ? launch_v5<3, 3, true>(qkv, out, B, L, Lq, H, s) : launch_v5<4, 3, true>(qkv, out, B, L, Lq, H, s);
+    if (mode & 16) return three ? launch_v5<3, 0, true>(qkv, out, B, L, Lq, H, s) : launch_v5<4, 0, true>(qkv, out, B, L, Lq, H, s);
     switch (mode & 3) {
         case 1: return three ? launch_v5<3, 1>(qkv, out, B, L, Lq, H, s) : launch_v5<4, 1>(qkv, out, B, L, Lq, H, s);
         case 2: return three ? launch_v5<3, 2>(qkv, out, B, L, Lq, H, s) : launch_v5<4, 2>(qkv, out, B, L, Lq, H, s);

@@ -1,0 +1,30 @@
+#!/usr/bin/env python3
+"""Attention variants (experiment build) against the fp64 statement of clip/model.py:184-188 at the ViT-L shapes, with the spiked keys of
+tests/test_hip_kernels.py:test_attention_f16 (rescale path, late-block reference move) and a row whose scores are all far below zero."""
+import ctypes, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+if "--exp" in sys.argv:
+    os.environ.setdefault("OVMR_HIP_LIB", os.path.join(ROOT, "ovmr_amd", "lib", "libovmr_hip_exp.so"))
+import torch
+from ovmr_amd import runtime
+lib = runtime.load_library()
+variants = [int(a) for a in sys.argv[1:] if a.lstrip("-").isdigit()] or [1, 3]
+p = lambda t: ctypes.c_void_p(t.data_ptr())
+s = lambda: ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+for B, L, H in ((2, 577, 16), (3, 257, 16), (1, 300, 4), (2, 1025, 2)):
+    g = torch.Generator().manual_seed(B * L + H)
+    qkv = torch.randn(B * L, 3 * H * 64, generator=g).half()
+    qkv[L // 2, H * 64:H * 64 + 64] *= 6.0
+    qkv[L - 70, H * 64:H * 64 + 64] *= 9.0
+    qkv[5, :64] = -qkv[:L, H * 64:H * 64 + 64].float().mean(0).half() * 40     # query 5 of head 0: scores far from zero
+    x = qkv.double().reshape(B, L, 3, H, 64)
+    q, k, v = x[:, :, 0].transpose(1, 2), x[:, :, 1].transpose(1, 2), x[:, :, 2].transpose(1, 2)
+    ref = (torch.softmax(q @ k.transpose(-1, -2) * 0.125, -1) @ v).transpose(1, 2).reshape(B * L, H * 64)
+    qd = qkv.cuda()
+    for var in variants:
+        out = torch.zeros(B * L, H * 64, dtype=torch.float16, device="cuda")
+        rc = lib.ovmr_debug_attention(0, var, p(qd), p(out), B, L, H, 0, s())
+        torch.cuda.synchronize()
+        err = (out.double().cpu() - ref).abs().max().item()
+        print(f"B {B} L {L} H {H} variant {var}: rc {rc} max abs err {err:.2e} finite {bool(torch.isfinite(out).all())}", flush=True)
