@@ -186,5 +186,10 @@ int launch_argmax_reduce(const float* partial, int tiles, const int* labels, int
 int launch_fusion_weights(const int* counts, const int* n_label, int C, float tau, float* out, hipStream_t s);
 int launch_scale_f16(const half_t* x, half_t* y, float scale, long n, hipStream_t s);
 int launch_preprocess_u8(const uint8_t* in, half_t* out, int B, int R, const float* mean3, const float* std3, hipStream_t s);
+// one-launch classifier head (head_fused.hip); -100: shape not taken
+size_t head_fused_ws_bytes(int B, int C);
+int head_fused_sync_ints();
+int launch_head_fused(const half_t* feats, int B, int D, float scale, const half_t* const* clf, int n_mod, int C, const float* w,
+                      float* out, half_t* raw_out, void* ws, int* sync, int n_cu, int max_grid, hipStream_t s);
 int launch_fused_softmax(const half_t* l0, const half_t* l1, const half_t* l2, const float* w, int n_mod,
                          float* out, int B, int C, hipStream_t s);

@@ -48,6 +48,9 @@ struct ovmr_handle {
     int gemm_variant = 8, attn_variant = 3;   // defaults = fastest verified kernels (tools/gemm_bench.py, tools/attn_bench.py); attention 3 falls back to 1 / 0 by shape
     int ln_fold = 1;                          // fold ln_1 / ln_2 of the fp16 towers into the consuming GEMM where the shape allows
     int xval_fused = 1;                       // cross-validation logits: row argmax fused into the GEMM epilogue (never stored)
+    int fused_head = 1;                       // ovmr_fused_logits / ovmr_zeroshot_logits as ONE launch (head_fused.hip); 0: scale + GEMMs + softmax
+    int head_max_grid = 0;                    // > 0 caps the fused head's grid (tests: workgroups then take several tiles)
+    int* head_sync = nullptr;                 // the fused head's device counters (zero between launches)
     float logit_scale_exp = 100.f;
     bool have_logit_scale = false;
 
@@ -356,6 +359,12 @@ int ovmr_create(const ovmr_model_desc* d, ovmr_handle** out) {
     h->G = d->image_resolution / d->vision_patch_size;
     h->L = h->G * h->G + 1;
     h->Kpad = (3 * d->vision_patch_size * d->vision_patch_size + 63) / 64 * 64;
+    const size_t sync_bytes = (size_t)head_fused_sync_ints() * sizeof(int);
+    if (hipMalloc((void**)&h->head_sync, sync_bytes) != hipSuccess || hipMemset(h->head_sync, 0, sync_bytes) != hipSuccess) {
+        delete h;
+        return OVMR_E_NOMEM;
+    }
+    h->owned.push_back(h->head_sync);
     *out = h;
     return 0;
 }
@@ -425,6 +434,8 @@ int ovmr_set_option(ovmr_handle* h, const char* key, int value) {
     }
     else if (!strcmp(key, "ln_fold")) h->ln_fold = value;
     else if (!strcmp(key, "xval_fused")) h->xval_fused = value;
+    else if (!strcmp(key, "fused_head")) h->fused_head = value;
+    else if (!strcmp(key, "head_max_grid")) h->head_max_grid = value;
     else if (!strcmp(key, "gelu_exact")) h->gelu_exact = value;
     else return fail(h, OVMR_E_NAME, "unknown option '%s'", key);
     return 0;
@@ -832,6 +843,16 @@ int ovmr_fused_logits(ovmr_handle* h, const void* feats_f16, int B, const void* 
         default: return fail(h, OVMR_E_ARG, "unknown eval mode %d", mode);
     }
     for (int m = 0; m < n_mod; ++m) if (!clf[m]) return fail(h, OVMR_E_ARG, "classifier %d is NULL for mode %d", m, mode);
+    // (up to 512 query rows and 4096 classes: every 64-row tile re-reads the classifier matrices and every workgroup merges its
+    //  rows' per-tile statistics, so beyond that the GEMM path's 256-row tiles win -- tools/head_bench.py; option fused_head = 2
+    //  takes the one-launch kernel at any size)
+    if (h->fused_head && ((B <= 512 && C <= 4096) || h->fused_head == 2) && head_fused_ws_bytes(B, C) <= h->ws_bytes) {
+        // one launch: scaled features staged once, the (up to) three products, both rounding points, softmax and weighted sum (head_fused.hip)
+        const half_t* cl[3] = {(const half_t*)clf[0], n_mod > 1 ? (const half_t*)clf[1] : nullptr, n_mod > 2 ? (const half_t*)clf[2] : nullptr};
+        const int rc = launch_head_fused((const half_t*)feats_f16, B, D, h->logit_scale_exp, cl, n_mod, C, mode == OVMR_MODE_FUSION ? w : nullptr,
+                                         out_f32, nullptr, h->ws, h->head_sync, h->n_cu, h->head_max_grid, s);
+        if (rc != -100) { CK(rc); return 0; }
+    }
     const int chunk = (int)std::min<long>(std::max<long>(1, h->logit_elems_cap / C), 65536);
     for (int b0 = 0; b0 < B; b0 += chunk) {
         const int Bc = std::min(chunk, B - b0);
@@ -856,6 +877,12 @@ int ovmr_zeroshot_logits(ovmr_handle* h, const void* feats_f16, int B, const voi
     if (!h->finalized) return fail(h, OVMR_E_STATE, "ovmr_finalize() has not been called");
     hipStream_t s = (hipStream_t)stream;
     const int D = h->d.embed_dim;
+    if (h->fused_head) {                           // scale, product and the fp16 rounding of the logits in one launch
+        const half_t* cl[3] = {(const half_t*)text_f16, nullptr, nullptr};
+        const int rc = launch_head_fused((const half_t*)feats_f16, B, D, h->logit_scale_exp, cl, 1, C, nullptr, nullptr, (half_t*)out_f16,
+                                         nullptr, nullptr, h->n_cu, 0, s);
+        if (rc != -100) { CK(rc); return 0; }
+    }
     for (int b0 = 0; b0 < B; b0 += 65536) {
         const int Bc = std::min(65536, B - b0);
         Carver c(h->ws);

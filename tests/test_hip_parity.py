@@ -417,7 +417,7 @@ def test_get_fusion_weight_coop_variant(golden, O):
 
 
 @pytest.mark.parametrize("model,D,cases", [
-    ("tiny", 128, ((6, 4, 5), (37, 3, 9), (1000, 4, 33), (130, 16, 256))),
+    ("tiny", 128, ((6, 4, 5), (37, 3, 9), (1000, 4, 33), (130, 16, 256), (1003, 2, 70))),
     ("ViT-B/16", 512, ((1000, 16, 256),)),     # BASELINE config 3 exactly: 1000 classes x 16 shots, query batch 256, embed_dim 512
 ])
 def test_fusion_head_vs_oracle(O, model, D, cases):
@@ -449,13 +449,39 @@ def test_fusion_head_vs_oracle(O, model, D, cases):
         bad = (fw - fw_ref).abs().max(dim=1).values > 1e-5
         assert int(bad.sum()) <= 2 * flips, f"C={C}: {int(bad.sum())} classes differ, {flips} near-tie rows"
         q = torch.nn.functional.normalize(centers[torch.arange(B) % C] + 0.3 * torch.randn(B, D, generator=g), dim=-1).half()
+        # both implementations of the head: ONE launch (head_fused.hip; also with its grid capped at 1 and 3 workgroups, so that a
+        # workgroup takes several tiles and the recompute queue of phase 2 runs) and the first five-launch path
         for mode in ("fusion", "text", "vision", "multimodal"):
             ref = O.inference_logits(q, clfs[0], clfs[1], clfs[2], fw_ref, ls, mode)
-            got = e.fused_logits(q, clfs[0], clfs[1], clfs[2], fw_ref, mode).cpu()
-            assert got.shape == (B, C) and got.dtype == torch.float32
-            assert_cosine(got.numpy(), ref.numpy(), 2e-4, f"{mode} C={C}")
-            frac_bad = float(((got - ref).abs() > 2e-3 + 0.07 * ref.abs()).float().mean())
-            assert frac_bad < 0.01, f"{mode}: {frac_bad:.3%} of probabilities off by more than one fp16 logit step"
+            outs = {}
+            for tag, fused, cap in (("one launch", 2, 0), ("one launch, grid 1", 2, 1), ("one launch, grid 3", 2, 3), ("five launches", 0, 0)):   # 2: at any size
+                e.set_option("fused_head", fused)
+                e.set_option("head_max_grid", cap)
+                got = outs[tag] = e.fused_logits(q, clfs[0], clfs[1], clfs[2], fw_ref, mode).cpu()
+                assert got.shape == (B, C) and got.dtype == torch.float32 and bool(torch.isfinite(got).all())
+                assert_cosine(got.numpy(), ref.numpy(), 2e-4, f"{mode} C={C} ({tag})")
+                frac_bad = float(((got - ref).abs() > 2e-3 + 0.07 * ref.abs()).float().mean())
+                assert frac_bad < 0.01, f"{mode} ({tag}): {frac_bad:.3%} of probabilities off by more than one fp16 logit step"
+            e.set_option("fused_head", 1)
+            e.set_option("head_max_grid", 0)
+            # the capped grids run the same arithmetic in another order of workgroups: bit-equal; the five-launch path sums K in another
+            # order, so a logit may land on the neighbouring fp16 value
+            assert torch.equal(outs["one launch"], outs["one launch, grid 1"]) and torch.equal(outs["one launch"], outs["one launch, grid 3"])
+            d = (outs["one launch"] - outs["five launches"]).abs()
+            assert float((d > 2e-3 + 0.07 * outs["five launches"].abs()).float().mean()) < 0.002, f"{mode}: the two head implementations disagree"
+        # the same call twice in a row (the device counters re-arm themselves) and a second stream's worth of calls interleaved
+        a = e.fused_logits(q, clfs[0], clfs[1], clfs[2], fw_ref, "fusion")
+        b = e.fused_logits(q, clfs[0], clfs[1], clfs[2], fw_ref, "fusion")
+        assert torch.equal(a, b)
+        # zero-shot raw logits (trainers/zsclip.py:58-59): h(h(scale f) . t), both paths
+        want = ((ls * q.float()).half().float() @ clfs[2].float().t()).half()
+        for fused in (1, 0):
+            e.set_option("fused_head", fused)
+            z = e.zeroshot_logits(q, clfs[2]).cpu()
+            assert z.shape == (B, C) and z.dtype == torch.float16
+            dz = (z.float() - want.float()).abs()
+            assert float((dz > 0.07).float().mean()) == 0.0 and float((dz > 0).float().mean()) < 0.02, f"zero-shot logits, fused_head {fused}"
+        e.set_option("fused_head", 1)
 
 
 def test_never_predicted_class_gets_uniform_weight():
