@@ -103,6 +103,12 @@ def parse(argv=None):
                     help="seconds a collective may take before the process group aborts this rank (it then exits non-zero; no retry)")
     ap.add_argument("--gelu-exact", type=int, default=int(os.environ.get("OVMR_GELU_EXACT", "0")),
                     help="1: QuickGELU with the reference's three fp16 rounding points; 0 (engine default): one rounding, fp32")
+    ap.add_argument("--output-dir", default="tmpfs",
+                    help="cfg.OUTPUT_DIR: where forward_prompt writes mm_classifiers.pt / visual_tokens.pt INSIDE the timed step (K23, "
+                         "trainers/mm_classifier_one_prompt.py:276-291).  'tmpfs' = a scratch directory under /dev/shm, removed at exit; '' = no files")
+    ap.add_argument("--presets", type=int, default=1,
+                    help="default invocation only (preset metric, one GPU): after the headline, run the other BASELINE.json configurations (c2, c3, "
+                         "c4 as one rank of eight, c5) for a few steps each as child processes and add their figures to the line as `presets`")
     ap.add_argument("--cpu-sample-classes", type=int, default=2, help="classes per CPU worker process and repetition (0: skip)")
     ap.add_argument("--cpu-threads", type=int, default=16, help="threads per CPU worker process")
     ap.add_argument("--cpu-reps", type=int, default=3)
@@ -154,7 +160,15 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world, timeout=to)
         dist_info = process_group_identity(dist, dev, backend, world)
 
-    spec, sd, pl, tok, model = make_model(args, dev, sharded)
+    out_dir = args.output_dir
+    if out_dir == "tmpfs":
+        import atexit
+        import shutil
+        import tempfile
+        base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
+        out_dir = tempfile.mkdtemp(prefix="ovmr_bench_", dir=base)
+        atexit.register(shutil.rmtree, out_dir, True)
+    spec, sd, pl, tok, model = make_model(args, dev, sharded, output_dir=out_dir)
     eng = model.engine
     C, S, Q, n_ctx = args.classes, args.shots, args.queries, 2
     R = spec.image_resolution
@@ -270,7 +284,9 @@ def main():
                        "parallelism": f"class/query sharding over {world} rank(s); all-gather rows + all-reduce counters"
                                       + (f" (process group {dist.get_backend()}, sharded path forced)" if args.force_dist and world == 1 else ""),
                        "preset": args.preset, "gemm_variant": args.gemm, "attn_variant": args.attn, "ln_fold": args.ln_fold, "gelu_exact": args.gelu_exact,
-                       "stream_text": args.stream_text, "encoder_reserve_images": args.batch, "encoder_chunk_images": eng.encode_chunk, "images_per_step": images_per_step},
+                       "stream_text": args.stream_text, "encoder_reserve_images": args.batch, "encoder_chunk_images": eng.encode_chunk, "images_per_step": images_per_step,
+                       "files_written_in_step": bool(out_dir) and not infer_only,
+                       "output_dir": ("tmpfs scratch (" + os.path.dirname(out_dir) + ")") if args.output_dir == "tmpfs" else out_dir},
             "dist": dist_info,
             "roofline": roof,
             "cpu_baseline": cpu,
@@ -282,6 +298,9 @@ def main():
                        "encoder_tflops_e2e_executed": round(value * flops_run / 1e12, 1),
                        "e2e_frac_of_fp16_mfma_peak": round(value * flops_run / 1e12 / (2500.0 * world), 4)},
         }
+        if args.presets and args.preset == "metric" and world == 1 and not args.force_dist:
+            torch.cuda.empty_cache()                    # (the children need at most ~40 GB of the 288: this process keeps its ~10 GB)
+            line["presets"] = run_presets(args)
         if cpu and cpu.get("value"):
             # one GPU against the CPUs the cgroup grants this job (cpu["cores"] threads), NOT against the whole host
             line["gpu_over_cpu"] = round(value / cpu["value"], 1)
@@ -293,6 +312,36 @@ def main():
 
 
 # ------------------------------------------------------------------------------------------
+def run_presets(args):
+    """The other BASELINE.json configurations on the same box, right behind the headline: each as a fresh child process of this script
+    (its own weights, images and engine; this process has released its GPU memory), a few steps each.  Returns {preset: {value, unit,
+    ms_per_step, steps, roofline_frac, workload}} -- or {"error": ...} for one that failed; the headline line does not depend on them."""
+    plan = (("c2", 3, 1), ("c3", 3, 1), ("c4", 2, 1), ("c5", 2, 1))
+    out = {}
+    for name, steps, warm in plan:
+        cmd = [sys.executable, os.path.abspath(__file__), "--preset", name, "--steps", str(steps), "--warmup", str(warm), "--no-cpu-baseline",
+               "--presets", "0", "--gelu-exact", str(args.gelu_exact), "--ln-fold", str(args.ln_fold)]
+        t0 = time.perf_counter()
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+            rows = [l for l in r.stdout.splitlines() if l.startswith('{"metric')]
+            if r.returncode != 0 or not rows:
+                out[name] = {"error": f"rc {r.returncode}: {(r.stderr or r.stdout)[-300:]}"}
+                continue
+            d = json.loads(rows[-1])
+            out[name] = {"value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "steps": d["steps"],
+                         "roofline_frac": (d.get("roofline") or {}).get("frac"), "workload": d["config"]["workload"],
+                         "wall_s_incl_setup": round(time.perf_counter() - t0, 1)}
+            if d.get("projection"):
+                out[name]["projected_images_per_s_all_ranks"] = d["projection"]["projected_images_per_s_all_ranks"]
+                out[name]["projection_excludes"] = d["projection"]["not_included"]
+            if d.get("phases"):
+                out[name]["phases"] = {k: v for k, v in d["phases"].items() if k.endswith("images_per_s") or k.endswith("_rank0") or "xval" in k or "head" in k}
+        except Exception as e:                               # noqa: BLE001
+            out[name] = {"error": repr(e)[:300]}
+    return out
+
+
 def make_model(args, dev, sharded=False, output_dir=""):
     """The job's model as bench.py times it: synthetic CLIP-init weights drawn on the device -- same shapes / std as
     ovmr_amd.synth, no biases / affine jitter, logit_scale = ln 100 -- random class-name tokens (seed 4321), n_ctx 2, tau 10, fusion mode."""

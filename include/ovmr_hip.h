@@ -191,6 +191,30 @@ float ovmr_logit_scale(const ovmr_handle* h);
  * fp32 arithmetic of torchvision bit for bit.  mean3 / std3 are HOST pointers to three floats.  R % 8 == 0.  Needs no handle. */
 int ovmr_preprocess_u8(const void* u8_hwc, int B, int R, const float* mean3, const float* std3, void* out_f16, ovmr_stream stream);
 
+/* Device half of the test transform, first part -- replaces Resize(max(INPUT.SIZE), INPUT.INTERPOLATION) + CenterCrop(INPUT.SIZE) of
+ * _build_transform_test (Dassl.pytorch/dassl/data/transforms/transforms.py:495-526; torchvision on PIL images, i.e. PIL.Image.resize +
+ * crop) for bicubic and bilinear interpolation, BIT-EQUAL to PIL: PIL's own two integer passes (22-bit fixed-point weights, uint8
+ * intermediate) over window / weight tables the host builds exactly as PIL does (ovmr_amd/resize.py).  One job per image:
+ *   in_offset   byte offset of its decoded uint8 [h, w, 3] pixels in `pixels` (device)
+ *   y0, ny      the input rows the R x R crop window needs;  tmp_offset: byte offset of its [ny, R, 3] intermediate in `tmp`
+ *   table       offset (in int32) of its size's table in `tables` (device):
+ *               [bounds_h R x 2 (xmin, n) | k_h R x ksize_h | bounds_v R x 2 (ymin - y0, n) | k_v R x ksize_v]
+ *   passthrough 1: `pixels` already holds the R x R crop of this image (resized on the host: nearest, or an image too large for the
+ *               upload ring) and is copied
+ * jobs: DEVICE array of n jobs; max_ny: the largest ny among them; out_u8: DEVICE uint8 [n, R, R, 3], the input of
+ * ovmr_preprocess_u8.  Needs no handle. */
+typedef struct ovmr_resize_job {
+    int64_t in_offset;
+    int64_t tmp_offset;
+    int32_t w, h;
+    int32_t y0, ny;
+    int32_t table;
+    int32_t ksize_h, ksize_v;
+    int32_t passthrough;
+} ovmr_resize_job;
+int ovmr_resize_crop_u8(const void* pixels, const ovmr_resize_job* jobs, int n, const int32_t* tables, void* tmp, int max_ny,
+                        void* out_u8, int R, ovmr_stream stream);
+
 /* Images per launch sequence of ovmr_encode_image after ovmr_finalize (<= max_images): a batch of MORE than max_images images is
  * encoded in chunks of this many (one that fits the workspace is a single launch sequence), chosen so that the 256-row-tile grids of the block GEMMs are whole rounds of the CUs and no launch has more than 600 row tiles (ViT-B/16 on 256 CUs: 775 of a
  * reserve of 775 or more, 665 of 768); ovmr_set_option(h, "enc_chunk", n) pins it (0 = automatic).  Chunks of at least 256

@@ -185,6 +185,9 @@ int launch_argmax_counts(const half_t* logits, int ld, const int* labels, int R,
 int launch_argmax_reduce(const float* partial, int tiles, const int* labels, int R, int C, int* tp, int* n_pred, hipStream_t s);
 int launch_fusion_weights(const int* counts, const int* n_label, int C, float tau, float* out, hipStream_t s);
 int launch_scale_f16(const half_t* x, half_t* y, float scale, long n, hipStream_t s);
+struct ovmr_resize_job;
+int launch_resize_crop_u8(const uint8_t* pixels, const ovmr_resize_job* jobs, int n, const int32_t* tables, uint8_t* tmp, int max_ny,
+                          uint8_t* out, int R, hipStream_t s);
 int launch_preprocess_u8(const uint8_t* in, half_t* out, int B, int R, const float* mean3, const float* std3, hipStream_t s);
 // one-launch classifier head (head_fused.hip); -100: shape not taken
 size_t head_fused_ws_bytes(int B, int C);

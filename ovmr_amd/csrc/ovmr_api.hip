@@ -450,6 +450,13 @@ int ovmr_preprocess_u8(const void* u8_hwc, int B, int R, const float* mean3, con
     return launch_preprocess_u8((const uint8_t*)u8_hwc, (half_t*)out_f16, B, R, mean3, std3, (hipStream_t)stream);
 }
 
+int ovmr_resize_crop_u8(const void* pixels, const ovmr_resize_job* jobs, int n, const int32_t* tables, void* tmp, int max_ny,
+                        void* out_u8, int R, ovmr_stream stream) {
+    if (n == 0) return 0;
+    if (!pixels || !jobs || !tables || !out_u8 || n < 0 || R <= 0 || max_ny < 0 || (max_ny > 0 && !tmp)) return OVMR_E_ARG;
+    return launch_resize_crop_u8((const uint8_t*)pixels, jobs, n, tables, (uint8_t*)tmp, max_ny, (uint8_t*)out_u8, R, (hipStream_t)stream);
+}
+
 int ovmr_set_weight(ovmr_handle* h, const char* name_c, const void* data, int dtype, int ndim,
                     const int64_t* shape, ovmr_stream stream) {
     if (!h || !name_c || !data || (dtype != OVMR_F16 && dtype != OVMR_F32) || ndim < 0 || ndim > 4) return OVMR_E_ARG;

@@ -31,6 +31,12 @@ class ModelDesc(ctypes.Structure):
                                    "transformer_layers", "n_ctx", "agg_layers")]
 
 
+class ResizeJob(ctypes.Structure):
+    """ovmr_resize_job (include/ovmr_hip.h)."""
+    _fields_ = [("in_offset", ctypes.c_int64), ("tmp_offset", ctypes.c_int64), ("w", c_i), ("h", c_i), ("y0", c_i), ("ny", c_i),
+                ("table", c_i), ("ksize_h", c_i), ("ksize_v", c_i), ("passthrough", c_i)]
+
+
 class TextGroup(ctypes.Structure):
     """ovmr_text_group (include/ovmr_hip.h)."""
     _fields_ = [("prompts_f16", c_p), ("ids", c_p), ("index", c_p), ("n", c_i), ("seq_len", c_i), ("normalize", c_i), ("out_f16", c_p)]
@@ -58,6 +64,7 @@ SIGNATURES = {
     "ovmr_zeroshot_logits": (c_i, [c_p, c_p, c_i, c_p, c_i, c_p, c_p]),
     "ovmr_logit_scale": (ctypes.c_float, [c_p]),
     "ovmr_preprocess_u8": (c_i, [c_p, c_i, c_i, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float), c_p, c_p]),
+    "ovmr_resize_crop_u8": (c_i, [c_p, c_p, c_i, c_p, c_p, c_i, c_p, c_i, c_p]),
     "ovmr_encode_chunk": (ctypes.c_int, [c_p]),
     "ovmr_encode_plan": (c_i, [c_p, c_i, ctypes.POINTER(c_i), c_i]),
     "ovmr_flops_per_image": (ctypes.c_double, [c_p]),
