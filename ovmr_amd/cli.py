@@ -176,6 +176,7 @@ def parse(argv=None):
     ap.add_argument("--workers", type=int, default=None,
                     help="decode worker processes of the pipelined loader (default: DATALOADER.NUM_WORKERS); 0 = decode in this thread")
     ap.add_argument("--prefetch", type=int, default=3, help="batches the workers decode ahead")
+    ap.add_argument("--host-resize", action="store_true", help="Resize + CenterCrop in the decode workers (PIL) instead of on the GPU (ovmr_resize_crop_u8; same bytes either way)")
     ap.add_argument("--fast-decode", action="store_true", help="JPEG draft mode (DCT-domain downscale): faster, pixels differ slightly from the reference's")
     ap.add_argument("opts", default=None, nargs=argparse.REMAINDER, help="modify config options using the command-line (KEY VALUE pairs)")
     return ap.parse_args(argv)
@@ -262,19 +263,20 @@ def main(argv=None) -> Dict[str, float]:
         pl_state = checkpoint.load_prompt_learner_state(args.model_dir, args.load_epoch)
     else:
         print("Note that load_model() is skipped as no pretrained model is given")       # :464-466
-    model = modules.CustomCLIP(cfg, classnames, clip_model, tokenizer=BPETokenizer(args.bpe_path),
-                               prompt_learner_state=pl_state, reserve=(batch, 256, max(1024, len(classnames))))
     import torch.distributed as dist
     rank, world = (dist.get_rank(), dist.get_world_size()) if dist.is_available() and dist.is_initialized() else (0, 1)
     workers = cfg.DATALOADER.NUM_WORKERS if args.workers is None else args.workers
     if workers > 0:
         from .loader import PipelinedFolderLoader
-        kw = dict(workers=workers, prefetch=args.prefetch, device=args.device, fast_decode=args.fast_decode, **tfm)
+        kw = dict(workers=workers, prefetch=args.prefetch, device=args.device, fast_decode=args.fast_decode, device_resize=not args.host_resize, **tfm)
         eval_loader = PipelinedFolderLoader(exemplars, batch // shots * shots, size, rank, world, len(classnames), **kw)
         test_loader = PipelinedFolderLoader(test_items, batch, size, **kw)
+        (test_loader if test_loader.bs >= eval_loader.bs else eval_loader).warm()   # the decode workers start while the engine takes the weights (one ring serves both)
     else:
         eval_loader = FolderLoader(exemplars, batch // shots * shots, size, rank, world, len(classnames), **tfm)
         test_loader = FolderLoader(test_items, batch, size, **tfm)
+    model = modules.CustomCLIP(cfg, classnames, clip_model, tokenizer=BPETokenizer(args.bpe_path),
+                               prompt_learner_state=pl_state, reserve=(batch, 256, max(1024, len(classnames))))
     evaluator = Classification(len(classnames), classnames, device=args.device)
     model.forward_prompt(eval_loader)        # the reference does this inside the first forward (:341-342); up front it keeps the two loaders' statistics apart
     labels = collections.deque()
@@ -291,8 +293,8 @@ def main(argv=None) -> Dict[str, float]:
         st = getattr(ld, "stats", None)
         if st:
             print(f"input pipeline, {name}: {st['images']} images in {st['wall_s']:.2f} s = {st['images_per_s']:.0f} img/s end to end "
-                  f"({st['workers']} decode workers), host blocked on decode {st['decode_wait_s']:.2f} s = "
-                  f"{100 * st['decode_bound_fraction']:.0f} % of the time")
+                  f"({st['workers']} decode workers, {st.get('device_resized', 0)} images resized on the GPU / {st.get('host_resized', 0)} by the workers), "
+                  f"host blocked on decode {st['decode_wait_s']:.2f} s = {100 * st['decode_bound_fraction']:.0f} % of the time")
             results[f"pipeline_{name.split()[0]}"] = st
     results["classnames"] = classnames
     return results

@@ -242,6 +242,12 @@ class PipelinedFolderLoader:
     def __len__(self):
         return (len(self.items) + self.bs - 1) // self.bs
 
+    def warm(self) -> "PipelinedFolderLoader":
+        """Start (or find) the decode pool now: the worker interpreters come up while the caller is still loading weights."""
+        if len(self.items):
+            self._pool()
+        return self
+
     def _pool(self) -> _Pool:
         cap = self.cap
         while True:
@@ -356,7 +362,7 @@ class PipelinedFolderLoader:
             for a, z in timers:
                 try:
                     gpu_ms += a.elapsed_time(z)
-                except RuntimeError:                 # an abandoned iteration leaves its last pair open
+                except (RuntimeError, ValueError):   # an abandoned iteration leaves its last pair open
                     pass
             if ok:
                 pool.busy = False                    # every task was answered: the pool serves the next pass

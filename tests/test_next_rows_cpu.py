@@ -384,3 +384,27 @@ def test_fewshot_draw_matches_the_reference():
             assert len(ex) == 7 * shots and all(len(set(labels[i:i + shots])) == 1 for i in range(0, len(ex), shots))
             assert set(p for p, _ in ex) == set(got)                       # the fill only repeats drawn images
     assert [p for p, _ in cli.fewshot_items(items, 4, 1)] != [p for p, _ in cli.fewshot_items(items, 4, 2)]
+
+
+def test_resize_tables_reproduce_pil_bit_for_bit():
+    """ovmr_amd/resize.py restates Pillow's 8-bit resampling (Resample.c: precompute_coeffs, normalize_coeffs_8bpc, the horizontal and
+    the vertical integer pass) for Resize(size) + CenterCrop(size); the numpy form of the two passes over ITS tables must equal
+    PIL.Image.resize + crop on every byte -- bicubic and bilinear, up- and down-scaling, odd aspect ratios, one-pixel images.
+    (The GPU kernel runs the same two passes over the same tables: tests/test_hip_loader.py holds it to PIL directly.)"""
+    from PIL import Image
+    from ovmr_amd import resize
+    from ovmr_amd._decode_worker import load_u8
+    rng = np.random.default_rng(5)
+    sizes = [(500, 375), (375, 500), (224, 224), (224, 300), (100, 37), (1200, 224), (1, 1), (2, 700), (1600, 1200), (223, 225)]
+    sizes += [(int(rng.integers(3, 1000)), int(rng.integers(3, 1000))) for _ in range(30)]
+    for w, h in sizes:
+        img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        for interp, R in (("bicubic", 224), ("bilinear", 224), ("bicubic", 96)):
+            want = load_u8(Image.fromarray(img), R, False, interp)
+            got = resize.resize_crop_reference(img, R, interp)
+            assert np.array_equal(want, got), f"{w} x {h} -> {R} ({interp})"
+    p = resize.plan(500, 375, 224)
+    assert p["ksize_h"] == p["ksize_v"] == 9 and p["y0"] == 0 and p["ny"] == 375 and p["table"].dtype == np.int32
+    assert resize.resized_size(500, 375, 224) == (298, 224) and resize.resized_size(375, 500, 224) == (224, 298)
+    with pytest.raises(ValueError):
+        resize.plan(10, 10, 224, "nearest")

@@ -18,27 +18,34 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
-def make_dataset(root, classes, train_per_class, val_per_class, seed=0):
-    """Smooth synthetic photographs (low-frequency fields + a class-coloured blob), 500 x 375 JPEGs like ImageNet's typical size."""
+def _write_class(job):
+    """One class folder of one split (a worker of make_dataset; numpy + PIL only)."""
     import numpy as np
     from PIL import Image
+    d, c, per, seed = job
     rng = np.random.default_rng(seed)
     yy, xx = np.mgrid[0:375, 0:500].astype(np.float32)
-    n = 0
-    for split, per in (("train", train_per_class), ("val", val_per_class)):
-        for c in range(classes):
-            d = os.path.join(root, split, f"n{c:04d}")
-            os.makedirs(d, exist_ok=True)
-            for i in range(per):
-                f = rng.uniform(0.004, 0.03, (3, 2))
-                ph = rng.uniform(0, 6.28, (3, 2))
-                img = np.stack([127 + 70 * np.sin(f[k, 0] * xx + ph[k, 0]) * np.cos(f[k, 1] * yy + ph[k, 1]) for k in range(3)], -1)
-                cx, cy = rng.uniform(100, 400), rng.uniform(80, 300)
-                blob = np.exp(-((xx - cx) ** 2 + (yy - cy) ** 2) / (2 * 60.0 ** 2))[..., None]
-                col = np.array([(37 * c) % 255, (91 * c) % 255, (53 * c) % 255], dtype=np.float32)
-                img = img * (1 - blob) + col * blob + rng.normal(0, 6, img.shape)
-                Image.fromarray(img.clip(0, 255).astype(np.uint8)).save(os.path.join(d, f"{i:04d}.JPEG"), quality=88)
-                n += 1
+    os.makedirs(d, exist_ok=True)
+    for i in range(per):
+        f = rng.uniform(0.004, 0.03, (3, 2))
+        ph = rng.uniform(0, 6.28, (3, 2))
+        img = np.stack([127 + 70 * np.sin(f[k, 0] * xx + ph[k, 0]) * np.cos(f[k, 1] * yy + ph[k, 1]) for k in range(3)], -1)
+        cx, cy = rng.uniform(100, 400), rng.uniform(80, 300)
+        blob = np.exp(-((xx - cx) ** 2 + (yy - cy) ** 2) / (2 * 60.0 ** 2))[..., None]
+        col = np.array([(37 * c) % 255, (91 * c) % 255, (53 * c) % 255], dtype=np.float32)
+        img = img * (1 - blob) + col * blob + rng.normal(0, 6, img.shape)
+        Image.fromarray(img.clip(0, 255).astype(np.uint8)).save(os.path.join(d, f"{i:04d}.JPEG"), quality=88)
+    return per
+
+
+def make_dataset(root, classes, train_per_class, val_per_class, seed=0):
+    """Smooth synthetic photographs (low-frequency fields + a class-coloured blob), 500 x 375 JPEGs like ImageNet's typical size;
+    written by a pool of processes (started before this process touches torch or the GPU)."""
+    from concurrent.futures import ProcessPoolExecutor
+    jobs = [(os.path.join(root, split, f"n{c:04d}"), c, per, seed * 100003 + si * 10007 + c)
+            for si, (split, per) in enumerate((("train", train_per_class), ("val", val_per_class))) for c in range(classes)]
+    with ProcessPoolExecutor(max_workers=min(16, len(os.sched_getaffinity(0)))) as ex:
+        n = sum(ex.map(_write_class, jobs))
     with open(os.path.join(root, "classnames.txt"), "w") as f:
         f.write("".join(f"n{c:04d} thing number {c}\n" for c in range(classes)))
     return n
@@ -54,6 +61,7 @@ def main():
     ap.add_argument("--dir", default="/tmp/ovmr_pipeline_bench")
     ap.add_argument("--compare-plain", action="store_true", help="also run the single-threaded loader (--workers 0)")
     ap.add_argument("--fast-decode", action="store_true")
+    ap.add_argument("--host-resize", action="store_true", help="also run every worker count with Resize + CenterCrop in the workers (the round-3/4 pipeline)")
     args = ap.parse_args()
     import torch
     from ovmr_amd import checkpoint, cli, synth
@@ -71,19 +79,21 @@ def main():
     bpe = os.path.join(args.dir, "bpe.txt.gz")
     make_synthetic_bpe(bpe)
     out = {}
-    for workers in (args.workers + [0] if args.compare_plain else args.workers):
-        odir = os.path.join(args.dir, f"out_w{workers}")
+    runs = [(w, False) for w in args.workers] + ([(w, True) for w in args.workers] if args.host_resize else []) + ([(0, False)] if args.compare_plain else [])
+    for workers, host in runs:
+        odir = os.path.join(args.dir, f"out_w{workers}{'_host' if host else ''}")
         t0 = time.perf_counter()
-        res = cli.main(["--root", data, "--clip-weights", os.path.join(args.dir, "clip.pt"), "--bpe-path", bpe, "--eval-only",
+        res = cli.main(["--root", data, "--trainer", "MM_CLS_OP", "--n_ctx", "2", "--eval_mode", "fusion", "--eval_tau", "10", "--clip-weights", os.path.join(args.dir, "clip.pt"), "--bpe-path", bpe, "--eval-only",
                         "--model-dir", os.path.join(args.dir, "ckpt"), "--load-epoch", "30", "--output-dir", odir,
-                        "--workers", str(workers)] + (["--fast-decode"] if args.fast_decode else []) +
-                       ["DATASET.NUM_SHOTS", str(args.shots), "TEST.BATCH_SIZE", str(args.batch)])
+                        "--workers", str(workers)] + (["--fast-decode"] if args.fast_decode else []) + (["--host-resize"] if host else []) +
+                       ["DATASET.NUM_SHOTS", str(args.shots), "DATALOADER.TEST.BATCH_SIZE", str(args.batch)])
         wall = time.perf_counter() - t0
         images = args.classes * (args.shots + args.val_per_class)
-        out[f"workers_{workers}"] = {"images": images, "wall_s_incl_model_setup": round(wall, 2),
+        tag = f"workers_{workers}" + ("_host_resize" if host else "")
+        out[tag] = {"images": images, "resize": "workers (PIL)" if host else "GPU (ovmr_resize_crop_u8)", "wall_s_incl_model_setup": round(wall, 2),
                                     "pipeline_exemplar": res.get("pipeline_exemplar"), "pipeline_test": res.get("pipeline_test"),
                                     "accuracy": res.get("accuracy")}
-        print(json.dumps(out[f"workers_{workers}"]), flush=True)
+        print(json.dumps(out[tag]), flush=True)
     if args.compare_plain:
         a = torch.load(os.path.join(args.dir, f"out_w{args.workers[0]}", "mm_classifiers.pt"), map_location="cpu")
         b = torch.load(os.path.join(args.dir, "out_w0", "mm_classifiers.pt"), map_location="cpu")
