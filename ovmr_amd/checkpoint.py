@@ -46,25 +46,75 @@ def prompt_learner_checkpoint_path(directory: str, epoch: Optional[int] = None, 
     return best
 
 
+class _Inert:
+    """Stands in for every class or function a checkpoint names that is not on the allow list below: constructing it, calling it and
+    restoring its state do nothing.  A reference-written checkpoint's scheduler / optimiser objects end up as these."""
+
+    def __init__(self, *args, **kwargs):
+        pass
+
+    def __call__(self, *args, **kwargs):
+        return _Inert()
+
+    def __setstate__(self, state):
+        pass
+
+    def __reduce__(self):
+        return (_Inert, ())
+
+
+def _restricted_pickle():
+    """A pickle-module stand-in for torch.load whose Unpickler resolves ONLY what tensors, containers and scalars need; any other
+    global becomes `_Inert`.  Nothing a file names is imported or executed, so a reference-written checkpoint (tensors plus pickled
+    scheduler objects) loads without trusting it."""
+    import collections
+    import pickle
+    import types
+
+    allowed_builtins = {"dict", "list", "tuple", "set", "frozenset", "int", "float", "bool", "str", "bytes", "bytearray", "complex"}
+    allowed_torch_utils = {"_rebuild_tensor_v2", "_rebuild_tensor", "_rebuild_parameter"}
+
+    class Unpickler(pickle.Unpickler):
+        def find_class(self, module, name):
+            if module == "collections" and name == "OrderedDict":
+                return collections.OrderedDict
+            if module == "builtins" and name in allowed_builtins:
+                return getattr(__import__("builtins"), name)
+            if module == "torch._utils" and name in allowed_torch_utils:
+                return getattr(torch._utils, name)
+            if module == "torch" and (name.endswith("Storage") or name in ("Size", "device") or isinstance(getattr(torch, name, None), torch.dtype)):
+                return getattr(torch, name)
+            return _Inert
+
+    def load(f, **kwargs):
+        return Unpickler(f, **kwargs).load()
+
+    return types.SimpleNamespace(Unpickler=Unpickler, load=load, __name__="ovmr_restricted_pickle")
+
+
 def _torch_load(path: str):
     """Tensors, ints and dicts are all the hot path reads from these files, so they are unpickled with weights_only=True: nothing in
     the file can run code.  Checkpoints written by the reference's save_checkpoint also pickle the optimiser state and Dassl's
-    scheduler OBJECTS (the warm-up scheduler and its `successor`), which weights_only refuses.  Such a file is loaded only when the
-    caller says it is trusted -- OVMR_TRUSTED_CHECKPOINTS=1 in the environment -- because full unpickling executes whatever the file
-    asks for (what the reference's load_checkpoint always does, Dassl.pytorch/dassl/utils/torchtools.py:66-97); otherwise this raises
-    with the way out."""
+    scheduler OBJECTS (the warm-up scheduler and its `successor`, Dassl.pytorch/dassl/utils/torchtools.py:27-74), which weights_only
+    refuses -- and that is the file `generate_classifier.sh --model-dir ... --load-epoch 30` points at.  Such a file is read with a
+    RESTRICTED unpickler (`_restricted_pickle`): tensors and containers load, every other pickled object becomes an inert placeholder,
+    no code from the file runs.  OVMR_TRUSTED_CHECKPOINTS=1 in the environment asks for torch's full unpickling instead (what the
+    reference's load_checkpoint always does, torchtools.py:66-97) -- only for files whose origin is trusted."""
     import pickle
     try:
         return torch.load(path, map_location="cpu", weights_only=True)
     except (pickle.UnpicklingError, RuntimeError) as e:
         why = str(e).splitlines()[0][:160]
-        if os.environ.get("OVMR_TRUSTED_CHECKPOINTS", "0") != "1":
-            raise RuntimeError(f'"{path}" holds pickled objects beyond tensors ({why}).  Loading it means FULL unpickling, which can '
-                               "execute code from the file: set OVMR_TRUSTED_CHECKPOINTS=1 if you trust where it came from, or "
-                               "re-save its state_dict alone (torch.save({'state_dict': ckpt['state_dict'], 'epoch': ...}))") from e
-        import warnings
-        warnings.warn(f'"{path}" needs full unpickling ({why}); OVMR_TRUSTED_CHECKPOINTS=1: loading it with weights_only=False')
-        return torch.load(path, map_location="cpu", weights_only=False)
+        if os.environ.get("OVMR_TRUSTED_CHECKPOINTS", "0") == "1":
+            import warnings
+            warnings.warn(f'"{path}" needs full unpickling ({why}); OVMR_TRUSTED_CHECKPOINTS=1: loading it with weights_only=False')
+            return torch.load(path, map_location="cpu", weights_only=False)
+        try:
+            return torch.load(path, map_location="cpu", weights_only=False, pickle_module=_restricted_pickle())
+        except Exception as e2:                      # noqa: BLE001
+            raise RuntimeError(f'"{path}" holds pickled objects beyond tensors ({why}) and the restricted reader could not load it either '
+                               f"({type(e2).__name__}: {e2}).  Set OVMR_TRUSTED_CHECKPOINTS=1 for full unpickling if you trust where "
+                               "the file came from, or re-save its state_dict alone") from e2
 
 
 def load_prompt_learner_checkpoint(directory: str, epoch: Optional[int] = None, name: str = "prompt_learner"):

@@ -13,17 +13,19 @@ config file says otherwise -- exactly what train.py does without its YAML files)
 `DATASET.SUBSAMPLE_CLASSES` (all | base | new, datasets/oxford_pets.py:141-202), `DATALOADER.TEST.BATCH_SIZE`, `DATALOADER.NUM_WORKERS`,
 `INPUT.SIZE / INTERPOLATION / PIXEL_MEAN / PIXEL_STD / TRANSFORMS`, `TRAINER.COCOOP.N_CTX`, `MODEL.BACKBONE.NAME`, `MODEL.INIT_WEIGHTS`,
 `EVAL_MODE`, `EVAL_TAU`, `SEED`, `OUTPUT_DIR`; training / optimiser keys are accepted and ignored; any other key raises.  yacs / Dassl
-are not needed.  Extra flags of this runner: `--clip-weights` (no download here), `--bpe-path`, `--eval-split / --test-split`, the
+are not needed; `--transforms` sets INPUT.TRANSFORMS as in train.py:69-70, train.py's remaining flags (`--source-domains --target-domains
+--fs_classifier --head --stage_num --visual_token_path`) are accepted and ignored.  Extra flags of this runner: `--clip-weights` (no download here), `--bpe-path`, `--eval-split / --test-split`, the
 input-pipeline knobs, `--exemplar-list`.  Data layout (datasets/imagenet.py:146-159):
 `<root>/<split>/<class folder>/<image>`; `<root>/classnames.txt` lines "<folder> <class name>" (optional: folder names
 are used otherwise).  The exemplar (eval) set is NUM_SHOTS images per class folder of `--eval-split` (default "train") drawn
 under `--seed` exactly as the reference's generate_fewshot_dataset draws them, the test set is every image of `--test-split`
 (default "val").
 
-Input pipeline (ovmr_amd/loader.py): `--workers` processes decode + resize + crop to uint8 into a page-locked shared ring, a side
-stream uploads a batch and runs ovmr_preprocess_u8 (normalise + fp16 on the GPU) while the encoder works on the previous one.
-JPEG decode on the host's cores remains the bound of the whole job (a few thousand images/s against ~29 k for the encoder): the
-runner prints end-to-end images/s and the fraction of the time the encoder sat idle.
+Input pipeline (ovmr_amd/loader.py): `--workers` processes DECODE into a page-locked shared ring, a side stream uploads a batch and runs
+ovmr_resize_crop_u8 (Resize + CenterCrop, bit-equal to PIL) and ovmr_preprocess_u8 (normalise + fp16) on the GPU while the encoder
+works on the previous one; `--host-resize` keeps the resize in the workers.  JPEG decode on the host's cores remains the bound of the
+whole job (profiles/r05e_pipeline_bench_device_vs_host_resize.log: 14.5 k images/s with 16 workers against ~30 k for the encoder): the
+runner prints end-to-end images/s and the share of the time the host waited for the decoders.
 """
 from __future__ import annotations
 
@@ -139,11 +141,46 @@ def layout_exemplars(few: Sequence[Tuple[str, int]], shots: int, seed: int = 1) 
         per.setdefault(it[1], []).append(it)
     fill = np.random.RandomState(seed if seed >= 0 else None)
     out = []
-    for its in per.values():
+    for label, its in per.items():
+        if len(its) > shots:
+            # forward_prompt groups rows purely by position (num_cls = B // S, label.reshape(num_cls, S)[:, 0],
+            # trainers/mm_classifier_one_prompt.py:237-240): one surplus row would shift every later class group.  The reference's
+            # RandomClassSampler emits exactly n_ins rows per class (samplers.py:117-181); a list with more is refused, not trimmed
+            raise ValueError(f"class {label} has {len(its)} exemplar rows, more than DATASET.NUM_SHOTS = {shots}")
         if len(its) < shots:
             its = its + [its[int(k)] for k in fill.choice(len(its), size=shots - len(its), replace=True)]
         out.extend(its)
     return out
+
+
+def read_exemplar_list(path: str, num_classes: int, shots: int) -> List[Tuple[str, int]]:
+    """`--exemplar-list`: one `<image path> <label>` per line.  Checked before anything is decoded: every label inside
+    [0, num_classes), every file present, at most NUM_SHOTS rows per class (fewer are filled up with replacement by
+    `layout_exemplars`, as RandomClassSampler does) -- a malformed list fails here with the offending line, not as shifted class
+    groups inside forward_prompt."""
+    few: List[Tuple[str, int]] = []
+    per: Dict[int, int] = {}
+    with open(path) as f:
+        for no, raw in enumerate(f, 1):
+            ln = raw.strip()
+            if not ln:
+                continue
+            parts = ln.rsplit(" ", 1)
+            if len(parts) != 2 or not parts[1].lstrip("-").isdigit():
+                raise SystemExit(f"{path}:{no}: expected `<image path> <label>`, got {ln!r}")
+            img, label = parts[0], int(parts[1])
+            if not 0 <= label < num_classes:
+                raise SystemExit(f"{path}:{no}: label {label} outside [0, {num_classes}) -- the labels are the class-folder indices BEFORE class subsampling")
+            if not os.path.isfile(img):
+                raise SystemExit(f"{path}:{no}: image {img!r} does not exist")
+            per[label] = per.get(label, 0) + 1
+            if per[label] > shots:
+                raise SystemExit(f"{path}:{no}: class {label} has more than DATASET.NUM_SHOTS = {shots} exemplars (the eval-set loader "
+                                 "carries exactly NUM_SHOTS rows per class; trim the list or raise NUM_SHOTS)")
+            few.append((img, label))
+    if not few:
+        raise SystemExit(f"{path}: no exemplars listed")
+    return few
 
 
 def parse(argv=None):
@@ -159,12 +196,23 @@ def parse(argv=None):
     ap.add_argument("--trainer", type=str, default="", help="name of trainer")
     ap.add_argument("--backbone", type=str, default="", help="name of CNN backbone")
     ap.add_argument("--eval-only", action="store_true", help="evaluation only")
-    ap.add_argument("--model-dir", type=str, default="", help="load model from this directory for eval-only mode")
+    ap.add_argument("--model-dir", type=str, default="", help="load model from this directory for eval-only mode.  A checkpoint written by the "
+                    "reference's save_checkpoint also pickles scheduler / optimiser objects: it is read with a restricted unpickler (tensors load, the "
+                    "objects become inert placeholders, no code from the file runs); OVMR_TRUSTED_CHECKPOINTS=1 asks for torch's full unpickling instead")
     ap.add_argument("--load-epoch", type=int, help="load model weights at this epoch for evaluation")
     ap.add_argument("--eval_tau", type=float)
     ap.add_argument("--eval_mode", type=str, default="multimodal")
     ap.add_argument("--n_ctx", type=int, help="number of ctx")
     ap.add_argument("--no-train", action="store_true")
+    # flags of train.py the generation / evaluation modes never read (DA / DG domains, training augmentations, the stage-1 classifier,
+    # head and stage number): accepted so that a reference command line runs unchanged, and ignored
+    ap.add_argument("--source-domains", type=str, nargs="+", help="(accepted, ignored)")
+    ap.add_argument("--target-domains", type=str, nargs="+", help="(accepted, ignored)")
+    ap.add_argument("--transforms", type=str, nargs="+", help="INPUT.TRANSFORMS (train.py:69-70): of the test transform only `normalize` depends on it")
+    ap.add_argument("--fs_classifier", type=str, default="", help="(accepted, ignored)")
+    ap.add_argument("--head", type=str, default="", help="(accepted, ignored)")
+    ap.add_argument("--stage_num", type=int, help="(accepted, ignored)")
+    ap.add_argument("--visual_token_path", type=str, default="visual token path", help="(accepted, ignored)")
     # this runner's own
     ap.add_argument("--clip-weights", required=True, help="OpenAI CLIP .pt (TorchScript archive or state dict); the reference downloads it by MODEL.BACKBONE.NAME")
     ap.add_argument("--bpe-path", default=os.environ.get("OVMR_BPE_PATH"))
@@ -194,8 +242,7 @@ def build_splits(cfg, eval_split: str = "train", test_split: str = "val", exempl
     all_names = read_classnames(root, folders)
     _, test_items = list_split(root, test_split)
     if exemplar_list:
-        with open(exemplar_list) as f:
-            few = [(ln.rsplit(" ", 1)[0], int(ln.rsplit(" ", 1)[1])) for ln in (l.strip() for l in f) if ln]
+        few = read_exemplar_list(exemplar_list, len(folders), shots)
     else:
         few = fewshot_items(eval_all, shots, seed)
     all_labels = sorted({l for _, l in few})                  # the label set `subsample_classes` splits (train_x, oxford_pets.py:160-168)

@@ -148,7 +148,7 @@ def setup_cfg(args) -> SimpleNamespace:
         merge_from_file(flat, args.config_file)                  # 2.
     for flag, key in (("root", "DATASET.ROOT"), ("output_dir", "OUTPUT_DIR"), ("seed", "SEED"), ("trainer", "TRAINER.NAME"),
                       ("backbone", "MODEL.BACKBONE.NAME"), ("init_weight", "MODEL.INIT_WEIGHTS"), ("n_ctx", "TRAINER.COCOOP.N_CTX"),
-                      ("eval_mode", "EVAL_MODE"), ("eval_tau", "EVAL_TAU")):
+                      ("eval_mode", "EVAL_MODE"), ("eval_tau", "EVAL_TAU"), ("transforms", "INPUT.TRANSFORMS")):   # (--transforms decides "normalize", transforms.py:514-518)
         if g(flag):                                              # 3. reset_cfg: `if args.x:` -- 0 / "" / None leave the cfg alone
             _set(flat, key, g(flag), f"--{flag}")
     merge_from_list(flat, g("opts") or [])                       # 4.

@@ -261,6 +261,29 @@ def test_subsample_classes_base_new(tmp_path):
     cfg = config.setup_cfg(NS(**base, opts=["DATASET.NUM_SHOTS", "3", "DATASET.SUBSAMPLE_CLASSES", "all"]))
     with pytest.raises(SystemExit):
         cli.build_splits(cfg, exemplar_list=str(lst))                                           # classes without exemplars
+    # ... and is validated before anything is decoded: forward_prompt groups rows by POSITION, so a class with more than NUM_SHOTS rows
+    # would shift every later class group; out-of-range labels and missing files fail with the offending line
+    full = got["all"][1]
+    ok = tmp_path / "ok.txt"
+    ok.write_text("".join(f"{p} {l}\n" for p, l in full))
+    names_all, ex_all, _ = cli.build_splits(cfg, exemplar_list=str(ok))
+    assert names_all == ordered and [l for _, l in ex_all] == [c for c in range(5) for _ in range(3)]
+    short = tmp_path / "short.txt"                                                               # two rows for class 1: filled up to three of ITS images
+    short.write_text("".join(f"{p} {l}\n" for i, (p, l) in enumerate(full) if i != 4))
+    _, ex_short, _ = cli.build_splits(cfg, exemplar_list=str(short))
+    assert [l for _, l in ex_short] == [c for c in range(5) for _ in range(3)]
+    assert {p.split("/")[-2] for p, l in ex_short if l == 1} == {"n02"}
+    for bad_lines, what in ((full + [full[4]], "more than DATASET.NUM_SHOTS"), (full[:-1] + [(full[-1][0], 5)], "outside"),
+                            (full[:-1] + [(full[-1][0], -1)], "outside"), (full[:-1] + [(str(tmp_path / "nope.png"), 4)], "does not exist")):
+        bad = tmp_path / "bad.txt"
+        bad.write_text("".join(f"{p} {l}\n" for p, l in bad_lines))
+        with pytest.raises(SystemExit, match=what):
+            cli.build_splits(cfg, exemplar_list=str(bad))
+    (tmp_path / "bad.txt").write_text("just-a-path-without-label\n")
+    with pytest.raises(SystemExit, match="expected"):
+        cli.build_splits(cfg, exemplar_list=str(tmp_path / "bad.txt"))
+    with pytest.raises(ValueError, match="more than DATASET.NUM_SHOTS"):
+        cli.layout_exemplars(full + [full[0]], 3, 1)
 
 
 def test_loader_list_form_k_transforms():
@@ -323,24 +346,48 @@ class _SchedulerLike:
         self.last_epoch = 30
 
 
-def test_full_unpickling_is_opt_in(tmp_path, monkeypatch):
-    """A checkpoint that pickles OBJECTS (what the reference's save_checkpoint writes: scheduler instances) is refused unless
-    OVMR_TRUSTED_CHECKPOINTS=1 says its origin is trusted; a tensors-only file never needs the opt-in."""
+_RAN = []
+
+
+def _note(msg):
+    _RAN.append(msg)
+
+
+class _Payload:
+    """What a hostile file would carry: unpickling it calls a function of the loader's process."""
+    def __reduce__(self):
+        return (_note, ("code from the file ran",))
+
+
+def test_object_checkpoints_load_without_running_code(tmp_path, monkeypatch):
+    """A checkpoint that pickles OBJECTS next to the weights (what the reference's save_checkpoint writes: scheduler instances --
+    the very file `--model-dir ... --load-epoch 30` names) loads by default through the restricted unpickler: same tensors, the
+    objects replaced by inert placeholders, and a callable smuggled into the file is NOT called.  OVMR_TRUSTED_CHECKPOINTS=1 switches
+    to torch's full unpickling (then the file's code does run); a tensors-only file takes weights_only either way."""
     from ovmr_amd import checkpoint
     pl = {k: torch.from_numpy(v) for k, v in synth.prompt_learner_state_dict(synth.SPECS["micro"], 2, 11, True).items()}
     d = tmp_path / "prompt_learner"
     d.mkdir()
-    torch.save({"state_dict": pl, "epoch": 30, "scheduler": _SchedulerLike()}, d / "model.pth.tar-30")
+    torch.save({"state_dict": pl, "epoch": 30, "scheduler": _SchedulerLike(), "optimizer": {"state": {0: {"exp_avg": torch.ones(3)}}, "hook": _Payload()},
+                "val_result": np.float64(0.5)}, d / "model.pth.tar-30")
     monkeypatch.delenv("OVMR_TRUSTED_CHECKPOINTS", raising=False)
-    with pytest.raises(RuntimeError, match="OVMR_TRUSTED_CHECKPOINTS"):
-        checkpoint.load_prompt_learner_state(str(tmp_path), 30)
+    _RAN.clear()
+    got, epoch, path = checkpoint.load_prompt_learner_checkpoint(str(tmp_path), 30)
+    assert epoch == 30 and path.endswith("model.pth.tar-30") and not _RAN
+    assert sorted(got) == sorted(pl) and all(torch.equal(got[k], pl[k]) and got[k].dtype == pl[k].dtype for k in pl)
+    raw = checkpoint._torch_load(str(d / "model.pth.tar-30"))
+    assert isinstance(raw["scheduler"], checkpoint._Inert) and isinstance(raw["optimizer"]["hook"], checkpoint._Inert)
+    assert torch.equal(raw["optimizer"]["state"][0]["exp_avg"], torch.ones(3))
     monkeypatch.setenv("OVMR_TRUSTED_CHECKPOINTS", "1")
     with pytest.warns(UserWarning, match="full unpickling"):
         got = checkpoint.load_prompt_learner_state(str(tmp_path), 30)
-    assert all(torch.equal(got[k], pl[k]) for k in pl)
+    assert all(torch.equal(got[k], pl[k]) for k in pl) and _RAN == ["code from the file ran"]
     monkeypatch.delenv("OVMR_TRUSTED_CHECKPOINTS")
     torch.save({"state_dict": pl, "epoch": 31, "scheduler": None}, d / "model.pth.tar-31")
     assert sorted(checkpoint.load_prompt_learner_state(str(tmp_path), 31)) == sorted(pl)
+    # the reference-written golden checkpoint (tests/golden/gen_checkpoints.py: Dassl's save_checkpoint) loads without the opt-in
+    ref_written = checkpoint.load_prompt_learner_state(CKPT, 30)
+    assert "cls_token" in ref_written and all(isinstance(v, torch.Tensor) for v in ref_written.values())
 
 
 def test_default_tokenizer_from_environment(tmp_path, monkeypatch):
