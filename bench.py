@@ -272,7 +272,12 @@ def main():
         own = [p["ms_per_step_own"] for p in per_rank]
         dist_info["rank_skew_ms"] = round(max(own) - min(own), 3)
     if rank == 0:
-        flops_img, flops_run = eng.flops_per_image(), eng.flops_per_image_executed()
+        flops_img = eng.flops_per_image()
+        # executed FLOPs per image of THIS job: every loader batch and every query batch through the plan the engine runs for it
+        n_ex, n_q, lb = (c1 - c0) * S, q1 - q0, args.classes_per_batch * S
+        fl = sum(eng.flops_executed(min(lb, n_ex - s0)) for s0 in range(0, 0 if infer_only else n_ex, lb))
+        fl += sum(eng.flops_executed(min(args.query_batch, n_q - s0)) for s0 in range(0, n_q, args.query_batch))
+        flops_run = fl / max(1, (0 if infer_only else n_ex) + n_q)
         line = {
             "metric": "images/sec ViT-B/16 encode+fusion, 1k-class×16-shot, 1/2/4/8 MI355X" if args.preset == "metric" else
                       f"images/sec, BASELINE.json configuration {args.preset}: {PRESETS[args.preset]['about']}",
@@ -715,7 +720,11 @@ def shard_of_world(args, model, spec, dev, keep=None):
     if keep is not None:
         keep.update(local_counts=emu.local_counts, exemplars=buf[:(c1 - c0) * S], queries=q, out=out, classes=(c0, c1), model=model)
     roof = measure_roofline(eng, spec, args, dev, (c1 - c0) * S, q1 - q0)
-    flops_img, flops_run = eng.flops_per_image(), eng.flops_per_image_executed()
+    flops_img = eng.flops_per_image()
+    lb = args.classes_per_batch * S
+    fl = sum(eng.flops_executed(min(lb, (c1 - c0) * S - s0)) for s0 in range(0, (c1 - c0) * S, lb))
+    fl += sum(eng.flops_executed(min(args.query_batch, q1 - q0 - s0)) for s0 in range(0, q1 - q0, args.query_batch))
+    flops_run = fl / n_rank
     value = n_rank / dt
     xval_flops = 3 * 2.0 * (c1 - c0) * S * C * D
     model._dist = None

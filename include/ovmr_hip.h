@@ -224,10 +224,13 @@ int ovmr_encode_chunk(const ovmr_handle* h);
 
 /* Closed-form FLOP counts.  ovmr_flops_per_image is the ALGORITHMIC count of the reference's
  * VisionTransformer.forward (every block over every token, clip/model.py:411-428: 35.127 GFLOP for ViT-B/16);
- * ovmr_flops_per_image_executed is what ovmr_encode_image launches: its last block runs attention / out_proj / MLP for the
- * CLS query row only (identical result), ~6 % fewer. */
+ * ovmr_flops_per_image_executed is what ovmr_encode_image launches for a batch that fills the reserve: its last block runs
+ * attention / out_proj / MLP for the CLS query row only (identical result), ~6 % fewer, and -- in launch sequences of at least 256
+ * images -- the Q projection too.  ovmr_flops_executed(h, B) is the count for ONE call of ovmr_encode_image on B images: the plan
+ * actually run (ovmr_encode_plan), the 256-image rule applied per launch sequence (a query batch of 128 projects Q for every token). */
 double ovmr_flops_per_image(const ovmr_handle* h);
 double ovmr_flops_per_image_executed(const ovmr_handle* h);
+double ovmr_flops_executed(const ovmr_handle* h, int B);
 double ovmr_flops_per_prompt(const ovmr_handle* h, int seq_len);
 
 /* Unit-test hooks: launch ONE kernel (no handle).  f32 selects the fp32 (aggregator) kernels;

@@ -923,6 +923,19 @@ double ovmr_flops_per_image_executed(const ovmr_handle* h) {
     const double last_run = 4.0 * L * W * W + 4.0 * L * W + 18.0 * W * W + (q_cls ? 2.0 * W * W : 2.0 * L * W * W);
     return ovmr_flops_per_image(h) - last_full + last_run;
 }
+double ovmr_flops_executed(const ovmr_handle* h, int B) {
+    if (!h || !h->finalized || B <= 0) return 0;
+    const ovmr_model_desc& d = h->d;
+    const double L = h->L, W = d.vision_width;
+    const double last_full = 24.0 * L * W * W + 4.0 * L * L * W;
+    double total = 0;
+    for (const int Bc : encode_plan(h, B)) {               // the launch sequences ovmr_encode_image runs for this batch
+        const bool q_cls = h->last_q_cls && Bc >= 256;
+        const double last_run = 4.0 * L * W * W + 4.0 * L * W + 18.0 * W * W + (q_cls ? 2.0 * W * W : 2.0 * L * W * W);
+        total += Bc * (ovmr_flops_per_image(h) - last_full + last_run);
+    }
+    return total;
+}
 double ovmr_flops_per_prompt(const ovmr_handle* h, int seq_len) {
     if (!h) return 0;
     const ovmr_model_desc& d = h->d;

@@ -69,6 +69,7 @@ SIGNATURES = {
     "ovmr_encode_plan": (c_i, [c_p, c_i, ctypes.POINTER(c_i), c_i]),
     "ovmr_flops_per_image": (ctypes.c_double, [c_p]),
     "ovmr_flops_per_image_executed": (ctypes.c_double, [c_p]),
+    "ovmr_flops_executed": (ctypes.c_double, [c_p, c_i]),
     "ovmr_flops_per_prompt": (ctypes.c_double, [c_p, c_i]),
     "ovmr_debug_gemm": (c_i, [c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, ctypes.c_float, c_i, c_i, c_p]),
     "ovmr_debug_lnfold": (c_i, [c_i, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_i, c_i, c_p, c_p, c_p]),
@@ -212,6 +213,10 @@ class Engine:
 
     def flops_per_image_executed(self) -> float:
         return float(self.lib.ovmr_flops_per_image_executed(self.h))
+
+    def flops_executed(self, B: int) -> float:
+        """FLOPs ONE encode_image call on B images launches (the plan actually run, the 256-image Q rule per launch sequence)."""
+        return float(self.lib.ovmr_flops_executed(self.h, int(B)))
 
     def flops_per_prompt(self, seq_len: int) -> float:
         return float(self.lib.ovmr_flops_per_prompt(self.h, seq_len))

@@ -764,8 +764,8 @@ def test_config_c2_vit_b16_hundred_classes_eight_shots(golden, O):
 
 def test_config_c2_hundred_classes_eight_shots(O):
     """BASELINE config 2 shape (100 classes x 8 shots) on the 'small' model with PLAIN random weights, shuffled class order, ragged
-    last batch (100 = 3*32 + 4): every classifier row against the oracle; the counters here are decided by noise (no alignment), so the
-    fusion weights are held to the kernel's own counters -- the exact comparison with the oracle is the ViT-B/16 test above."""
+    last batch (100 = 3*32 + 4): every classifier row against the oracle; the fusion weights against the kernel's own counters and, on
+    the (at least 80) classes no near-tied argmax of the oracle can touch, against the oracle's exactly."""
     from ovmr_amd import modules
     spec, C, S = synth.SPECS["small"], 100, 8
     cm = _clip("small")
@@ -794,8 +794,10 @@ def test_config_c2_hundred_classes_eight_shots(O):
     for k in ("mm_classifier", "vision_classifier", "text_classifier"):
         affected |= near_tie_classes(O.cross_validation_logits(r["eval_feat4cls"], r[k].half(), ls).float().numpy(), 0.26)
     ok = np.array([c not in affected for c in range(C)])
-    if ok.any():                                                    # whatever no near-tie can touch agrees exactly
-        np.testing.assert_allclose(fw.cpu().numpy()[ok], r["fusion_weight"].numpy()[ok], atol=1e-5)
+    # 86 of the 100 classes are out of reach of every near-tied argmax of the oracle on this job (a pure function of the seeds): they
+    # hold the fusion weights to the ORACLE's exactly -- and the check cannot quietly become empty
+    assert ok.sum() >= 80, f"only {int(ok.sum())} classes free of near-ties: this job no longer pins the fusion weights"
+    np.testing.assert_allclose(fw.cpu().numpy()[ok], r["fusion_weight"].numpy()[ok], atol=1e-5)
 
 
 def test_config_c4_sixty_four_shots(O):
@@ -929,6 +931,42 @@ def test_config_c5_vit_l14_336_generation_end_to_end(O, tmp_path):
     np.testing.assert_allclose(saved["fusion_weight"].numpy(), r["fusion_weight"].numpy(), atol=1e-5)
     ref = O.inference_logits(qf, r["mm_classifier"].half(), r["vision_classifier"].half(), r["text_classifier"].half(), r["fusion_weight"], ls, "fusion")
     assert_cosine(outs["fusion"].numpy(), ref.numpy(), 5 * COS_TOL, "fusion")
+    del model, cm
+    torch.cuda.empty_cache()
+
+
+@pytest.mark.timeout(2400)
+def test_config_c5_vit_l14_336_thirty_two_shots(O, tmp_path):
+    """BASELINE config 5's SHOT COUNT behind the real tower: ViT-L/14@336px, 2 classes x 32 shots -- the 34-token fp32 aggregator
+    (n_ctx + 32) fed with the features of 64 images through 24 blocks of width 1024 (one launch sequence of 64 images x 577 tokens).
+    Features, visual tokens and the three classifier rows against the oracle's forward_prompt on the same inputs; the fusion weights
+    against the kernel's own counters (two classes: the argmax margins are whatever random weights give)."""
+    from ovmr_amd import modules
+    spec = synth.SPECS["ViT-L/14@336px"]
+    C, S, tau = 2, 32, 10.0
+    sd_np = synth.clip_state_dict(spec, SEED, jitter=True)
+    pl_np = synth.prompt_learner_state_dict(spec, 2, SEED, True)
+    tok = torch.from_numpy(synth.class_token_ids(C, seed=31))
+    labels = np.repeat(np.array([1, 0]), S)
+    img = torch.from_numpy(synth.images(C * S, 336, 1234, labels, 0.8, tile=14))
+    cm = modules.CLIPModel({k: torch.from_numpy(v) for k, v in sd_np.items()}, spec)
+    cfg = modules.make_cfg(n_ctx=2, num_shots=S, eval_tau=tau, output_dir=str(tmp_path), size=336)
+    model = modules.CustomCLIP(cfg, tok, cm, prompt_learner_state={k: torch.from_numpy(v) for k, v in pl_np.items()}, reserve=(64, 8, 8))
+    mm, v, fw = model.forward_prompt([{"img": img, "label": torch.from_numpy(labels)}])
+    sd = O.convert_weights(O.to_torch(sd_np), "fp16")
+    torch.set_num_threads(min(32, os.cpu_count()))
+    with torch.no_grad():
+        r = O.forward_prompt(img, torch.from_numpy(labels), tok, sd, O.to_torch(pl_np), 2, tau, C, "fp16")
+    assert model.visual_tokens.shape == (C, 2, 768)
+    assert_cosine(model.eval_feat4cls.float().cpu().flatten(0, 1).numpy(), r["eval_feat4cls"].float().flatten(0, 1).numpy(), COS_TOL, "eval_feat4cls")
+    assert_cosine(model.visual_tokens.float().cpu().flatten(0, 1).numpy(), r["visual_tokens"].float().flatten(0, 1).numpy(), COS_TOL, "visual tokens (aggregator sequence 34)")
+    assert_cosine(mm.float().cpu().numpy(), r["mm_classifier"].numpy(), COS_TOL, "mm")
+    assert_cosine(v.float().cpu().numpy(), r["vision_classifier"].numpy(), COS_TOL, "vision")
+    assert_cosine(model.zero_shot_classifier.float().cpu().numpy(), r["text_classifier"].numpy(), COS_TOL, "text")
+    counts = model.xval_counts.cpu()
+    assert int(counts[:, 1].sum()) == 3 * C * S
+    f1 = torch.stack([O.f1_from_counts(counts[m, 0], counts[m, 1], torch.full((C,), S)) for m in range(3)], -1)
+    np.testing.assert_allclose(fw.cpu().numpy(), (tau * f1).softmax(-1).numpy(), atol=1e-6)
     del model, cm
     torch.cuda.empty_cache()
 
