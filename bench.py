@@ -303,7 +303,8 @@ def main():
                        "encoder_tflops_e2e_executed": round(value * flops_run / 1e12, 1),
                        "e2e_frac_of_fp16_mfma_peak": round(value * flops_run / 1e12 / (2500.0 * world), 4)},
         }
-        if args.presets and args.preset == "metric" and world == 1 and not args.force_dist:
+        headline_job = (args.model, args.classes, args.shots, args.queries) == ("ViT-B/16", 1000, 16, 4096)
+        if args.presets and args.preset == "metric" and headline_job and world == 1 and not args.force_dist:
             torch.cuda.empty_cache()                    # (the children need at most ~40 GB of the 288: this process keeps its ~10 GB)
             line["presets"] = run_presets(args)
         if cpu and cpu.get("value"):

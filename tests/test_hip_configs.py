@@ -20,6 +20,7 @@ from ovmr_amd import synth
 
 pytestmark = pytest.mark.gpu
 SEED = 11
+PINNED_MIN = 0.9          # share of the headline job's classes whose six argmax counters the CPU restatement fixes to one value
 
 
 @pytest.fixture(scope="module")
@@ -28,8 +29,17 @@ def O():
     return ovmr_oracle
 
 
+def _ulp_margin(logits, ulps=3):
+    """Per-row margin of `ulps` fp16 steps AT the row maximum: two correct implementations of h(h(f . c) * scale) differ by the
+    accumulation order of the dot product, i.e. by one step of h(acc), carried through the second rounding -- at most 2 steps of the
+    result; 3 leaves slack.  (0.13 = 2 steps at |logit| in [64, 128): the fixed margin the larger jobs use.)"""
+    top = np.abs(logits.max(1, keepdims=True)).astype(np.float16)
+    return ulps * np.spacing(np.maximum(top, np.float16(2.0 ** -10))).astype(np.float32)
+
+
 def _count_bounds(logits, row_labels, C, margin):
-    """[lo, hi] for tp and n_pred of every class when an argmax may land on any class within `margin` of the row maximum."""
+    """[lo, hi] for tp and n_pred of every class when an argmax may land on any class within `margin` (a scalar, or one value per
+    row as [R, 1]) of the row maximum."""
     top = logits.max(1, keepdims=True)
     cand = logits >= top - margin
     sure = cand.sum(1) == 1
@@ -54,7 +64,7 @@ def test_headline_config_bench_job_vs_oracle(O):
       * 4 sampled classes: image features, multimodal / vision / text classifier rows and visual tokens against the oracle
         (64 images + 12 prompts of CPU work),
       * ALL 3 x 2 x 1000 argmax counters against a CPU restatement on the same fp16 features / classifier rows
-        (an argmax may land on any class within 2 fp16 steps of the row maximum: bounds per counter); the number of classes whose
+        (an argmax may land on any class within 3 fp16 steps of the row maximum: bounds per counter); the number of classes whose
         counters the bounds pin to a single value is printed and must be at least 90 %,
       * fusion weights = softmax(tau * F1(counters)) exactly,
       * 8 query rows of the fused output against the oracle."""
@@ -108,14 +118,16 @@ def test_headline_config_bench_job_vs_oracle(O):
     pinned = np.ones(C, dtype=bool)                  # classes whose six counters the restatement fixes to ONE value (no near-tie can reach them)
     for m, clf in enumerate((mm, v, t)):
         lg = _fp16_logits(f_cpu, clf.cpu(), ls)
-        tp_lo, tp_hi, n_lo, n_hi = _count_bounds(lg, row_lab, C, 0.13)
+        tp_lo, tp_hi, n_lo, n_hi = _count_bounds(lg, row_lab, C, _ulp_margin(lg))      # 3 fp16 steps at each row's own maximum
         assert counts[m, 1].sum() == C * S
         assert ((counts[m, 0] >= tp_lo) & (counts[m, 0] <= tp_hi)).all(), f"tp of classifier {m}"
         assert ((counts[m, 1] >= n_lo) & (counts[m, 1] <= n_hi)).all(), f"n_pred of classifier {m}"
         pinned &= (tp_lo == tp_hi) & (n_lo == n_hi)
+        print(f"  classifier {m}: row maxima {float(lg.max(1).min()):.2f} .. {float(lg.max(1).max()):.2f}, "
+              f"{int((tp_lo == tp_hi).sum())} tp / {int((n_lo == n_hi).sum())} n_pred counters pinned")
     # how much of the job the bounds pin EXACTLY: for these classes lo == hi, i.e. the HIP counters equal the CPU restatement's
-    print(f"headline job: {int(pinned.sum())} of {C} classes have all six counters pinned exactly (no argmax within 2 fp16 steps touches them)")
-    assert pinned.sum() >= 0.9 * C, f"only {int(pinned.sum())} of {C} classes are pinned exactly"
+    print(f"headline job: {int(pinned.sum())} of {C} classes have all six counters pinned exactly (no argmax within 3 fp16 steps of a row maximum touches them)")
+    assert pinned.sum() >= PINNED_MIN * C, f"only {int(pinned.sum())} of {C} classes are pinned exactly"
     f1 = torch.stack([O.f1_from_counts(torch.from_numpy(counts[m, 0]), torch.from_numpy(counts[m, 1]), torch.full((C,), S))
                       for m in range(3)], -1)
     np.testing.assert_allclose(fw.cpu().numpy(), (10.0 * f1).softmax(-1).numpy(), atol=1e-6)
@@ -213,7 +225,7 @@ def test_config_c4_vitb16_sixty_four_shots_one_rank_of_eight(O):
       * rank 0 ends with the whole job's bits (rows, tokens, counters, fusion weights) -- asserted inside shard_of_world;
       * 3 sampled classes (2 of rank 0, 1 of rank 5): features, mm / vision / text rows, visual tokens against the oracle;
       * ALL 3 x 2 x 5040 counters of the whole job AND rank 0's own votes against the CPU restatement's bounds, 8 064 rows at a time
-        (an argmax may land on any class within 2 fp16 steps of the row maximum);
+        (an argmax may land on any class within 3 fp16 steps of the row maximum; the share of classes pinned to one value is printed, >= 90 %);
       * fusion weights = softmax(tau * F1(counters)) exactly;
       * the four EVAL_MODEs on 8 queries against the oracle (oracle features, the job's classifiers and weights)."""
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -262,13 +274,14 @@ def test_config_c4_vitb16_sixty_four_shots_one_rank_of_eight(O):
     n_local = (C // N) * S
     chunk = 8064                                                                  # 126 classes: rank boundaries fall on chunk boundaries
     assert n_local % chunk == 0
+    pinned = np.ones(C, dtype=bool)
     for m, clf in enumerate((mm, v, t)):
         clf_cpu = clf.cpu()
         acc = np.zeros((4, C), dtype=np.int64)
         for r0 in range(0, C * S, chunk):
             lg = _fp16_logits(f_cpu[r0:r0 + chunk], clf_cpu, ls)
             row_lab = np.repeat(np.arange(r0 // S, (r0 + chunk) // S), S)
-            acc += np.stack(_count_bounds(lg, row_lab, C, 0.13))
+            acc += np.stack(_count_bounds(lg, row_lab, C, _ulp_margin(lg)))
             if r0 + chunk == n_local:
                 tp_lo, tp_hi, n_lo, n_hi = acc
                 assert local_counts[m, 1].sum() == n_local
@@ -278,6 +291,7 @@ def test_config_c4_vitb16_sixty_four_shots_one_rank_of_eight(O):
         assert counts_full[m, 1].sum() == C * S
         assert ((counts_full[m, 0] >= tp_lo) & (counts_full[m, 0] <= tp_hi)).all(), f"tp of classifier {m}"
         assert ((counts_full[m, 1] >= n_lo) & (counts_full[m, 1] <= n_hi)).all(), f"n_pred of classifier {m}"
+        pinned &= (tp_lo == tp_hi) & (n_lo == n_hi)
     f1 = torch.stack([O.f1_from_counts(torch.from_numpy(counts_full[m, 0]), torch.from_numpy(counts_full[m, 1]), torch.full((C,), S))
                       for m in range(3)], -1)
     np.testing.assert_allclose(fw.cpu().numpy(), (10.0 * f1).softmax(-1).numpy(), atol=1e-6)
@@ -294,6 +308,8 @@ def test_config_c4_vitb16_sixty_four_shots_one_rank_of_eight(O):
         assert out.shape == (8, C)
         assert_cosine(out.numpy(), want.numpy(), COS_TOL, f"{mode} rows at C = {C}")
     m.cfg.EVAL_MODE = "fusion"
+    print(f"c4 job: {int(pinned.sum())} of {C} classes have all six counters pinned exactly")
+    assert pinned.sum() >= PINNED_MIN * C
     print(f"c4 at ViT-B/16: rank 0 of {N}: {line['value']:.0f} img/s, generation {line['phases']['generation_images_per_s']:.0f} img/s, "
           f"xval {line['phases']['xval_counts_fusion_weights_ms']:.2f} ms")
     del keep, model, m

@@ -92,7 +92,7 @@ def test_bench_line_proves_its_process_group(tmp_path):
     import json
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     base = [sys.executable, os.path.join(repo, "bench.py"), "--classes", "12", "--shots", "4", "--queries", "32", "--query-batch", "16",
-            "--steps", "1", "--warmup", "1", "--no-cpu-baseline"]
+            "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--presets", "0"]
     lines = {}
     for tag, extra in (("dist", ["--force-dist", "--dist-timeout", "120"]), ("plain", [])):
         env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0")

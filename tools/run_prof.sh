@@ -14,25 +14,31 @@ cp gpurun_out/${T}_pmc_gemm/summary.json profiles/${T}_pmc_gemm_v108.json
 VARIANTS="1 3" bash tools/pmc_attn.sh gpurun_out/${T}_pmc_attn > gpurun_out/${T}_pmc_attn.log 2>&1
 cp gpurun_out/${T}_pmc_attn/summary.json profiles/${T}_pmc_attn.json
 timeout 900 python bench.py > gpurun_out/${T}_bench.log 2>&1; grep '^{"metric' gpurun_out/${T}_bench.log > profiles/${T}_bench_n1.json; cut -c1-200 profiles/${T}_bench_n1.json
-# round 4: the small-shard configuration, the 8-rank projection and the one-rank RCCL line of the same build on the same box
-timeout 600 python bench.py --preset c2 --no-cpu-baseline > gpurun_out/${T}_c2.log 2>&1; grep '^{"metric' gpurun_out/${T}_c2.log > profiles/${T}_bench_c2.json
-timeout 900 python bench.py --emulate-world 8 --no-cpu-baseline > gpurun_out/${T}_emu8.log 2>&1; grep '^{"metric' gpurun_out/${T}_emu8.log > profiles/${T}_emulated_world8.json
-timeout 900 python bench.py --force-dist --no-cpu-baseline > gpurun_out/${T}_fd.log 2>&1; grep '^{"metric' gpurun_out/${T}_fd.log > profiles/${T}_bench_n1_force_dist_rccl.json
+# (the default bench line above carries c2 / c3 / c4 / c5 as `presets`)  The 8-rank projection, the one-rank RCCL line and the 2-rank line
+# over gloo on this one GPU (launched exactly as the driver launches N > 1: per-rank times and the collectives in `dist`) of the same build, same box
+timeout 900 python bench.py --emulate-world 8 --no-cpu-baseline --presets 0 > gpurun_out/${T}_emu8.log 2>&1; grep '^{"metric' gpurun_out/${T}_emu8.log > profiles/${T}_emulated_world8.json
+timeout 900 python bench.py --force-dist --no-cpu-baseline --presets 0 > gpurun_out/${T}_fd.log 2>&1; grep '^{"metric' gpurun_out/${T}_fd.log > profiles/${T}_bench_n1_force_dist_rccl.json
+OVMR_DIST_BACKEND=gloo timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --steps 3 --warmup 1 > gpurun_out/${T}_gloo2.log 2>&1; grep '^{"metric' gpurun_out/${T}_gloo2.log > profiles/${T}_bench_gloo_2ranks_one_gpu.json
+timeout 600 python tools/head_bench.py > profiles/${T}_head_bench.log 2>&1
+timeout 600 python tools/attn_bench.py --variants 1 3 > profiles/${T}_attn_bench.log 2>&1
+bash tools/pmc_attn_l577.sh gpurun_out/${T}_pmc_attn_l577 > gpurun_out/${T}_pmc_attn_l577.log 2>&1; cp gpurun_out/${T}_pmc_attn_l577/summary.json profiles/${T}_pmc_attn_l577.json
+timeout 900 python tools/pipeline_bench.py --workers 16 --host-resize > gpurun_out/${T}_pipeline.log 2>&1; grep -E "^input pipeline|usable" gpurun_out/${T}_pipeline.log > profiles/${T}_pipeline_bench.log
 cd /tmp; export TMPDIR=/tmp
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${T}_stats -- python3 $R/bench.py --steps 3 --warmup 1 --cpu-sample-classes 0 > $R/gpurun_out/${T}_stats_bench.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${T}_stats -- python3 $R/bench.py --steps 3 --warmup 1 --cpu-sample-classes 0 --presets 0 > $R/gpurun_out/${T}_stats_bench.log 2>&1
 cd $R
 f=$(find gpurun_out/${T}_stats -name "*kernel_stats.csv" | head -1); cp $f profiles/${T}_rocprofv3_kernel_stats_bench_full.csv; head -6 $f | cut -c1-200
 grep '^{"metric' gpurun_out/${T}_stats_bench.log > profiles/${T}_bench_under_rocprof.json
 python3 tools/dominant_by_grid.py $(find gpurun_out/${T}_stats -name "*kernel_trace.csv" | head -1) profiles/${T}_bench_under_rocprof.json profiles/${T}_dominant_kernel_by_grid.json > /dev/null
-rm -rf gpurun_out/${T}_pmc_gemm/*/ gpurun_out/${T}_pmc_attn/*/ gpurun_out/${T}_stats     # raw counter / trace CSVs: large, the summaries are kept
+rm -rf gpurun_out/${T}_pmc_gemm/*/ gpurun_out/${T}_pmc_attn/*/ gpurun_out/${T}_pmc_attn_l577/*/ gpurun_out/${T}_stats     # raw counter / trace CSVs: large, the summaries are kept
 mkdir -p gpurun_out/${T}_keep; cp profiles/${T}_* gpurun_out/${T}_keep/     # gpurun merges only gpurun_out/ back: copy gpurun_out/<tag>_keep/* into profiles/ afterwards
 python3 - <<PY
 import json
 d = json.load(open("profiles/${T}_bench_n1.json"))
 r = d["roofline"]
-for f, k in (("bench_c2", "value"), ("emulated_world8", "projected_speedup"), ("bench_n1_force_dist_rccl", "value")):
+for f, k in (("emulated_world8", "projected_speedup"), ("bench_n1_force_dist_rccl", "value"), ("bench_gloo_2ranks_one_gpu", "value")):
     try: print(f, json.load(open("profiles/${T}_%s.json" % f))[k])
     except Exception as e: print(f, "failed", e)
+print("presets:", {k: v.get("value", v.get("error")) for k, v in (d.get("presets") or {}).items()})
 print("bench:", d["value"], "img/s; c_fc", r["avg_launch_us"], "us, frac", r["frac"], "mfma_busy", r.get("mfma_busy_frac"), "lds_conflict", r.get("lds_conflict_frac"), "hbm GB/s", r.get("hbm_gbps"))
 d = json.load(open("profiles/${T}_bench_under_rocprof.json"))
 print("under rocprof:", d["value"], d["roofline"]["avg_launch_us"], d["roofline"]["launches_per_step"], d["roofline"]["frac"])
