@@ -76,7 +76,6 @@ def parse(argv=None):
     ap.add_argument("--last-q-cls", type=int, default=1, help="last vision block: Q projected for the CLS rows only (1) or for every token (0)")
     ap.add_argument("--enc-chunk", type=int, default=0, help="images per launch sequence of the image tower: 0 = the engine's choice (<= --batch, whole "
                     "rounds of tiles: ovmr_encode_chunk), n pins it")
-    ap.add_argument("--qkv-sub", type=int, default=1, help="in_proj + attention of a vision block per sub-chunk of the launch sequence (engine option qkv_sub)")
     ap.add_argument("--overlap", type=int, default=-1, help="two query batches in flight on two streams (CustomCLIP.forward_batches): "
                     "1 / 0 force it on / off, -1 = the module's rule (batches of at most 384 images)")
     ap.add_argument("--classes-per-batch", type=int, default=DEFAULT_CLASSES_PER_BATCH,
@@ -374,7 +373,6 @@ def make_model(args, dev, sharded=False, output_dir=""):
     eng.set_option("gemm", args.gemm)
     eng.set_option("attn", args.attn)
     eng.set_option("ln_fold", args.ln_fold)
-    eng.set_option("qkv_sub", args.qkv_sub)
     return spec, sd, pl, tok, model
 
 

@@ -48,7 +48,6 @@ struct ovmr_handle {
     int gemm_variant = 8, attn_variant = 3;   // defaults = fastest verified kernels (tools/gemm_bench.py, tools/attn_bench.py); attention 3 falls back to 1 / 0 by shape
     int ln_fold = 1;                          // fold ln_1 / ln_2 of the fp16 towers into the consuming GEMM where the shape allows
     int xval_fused = 1;                       // cross-validation logits: row argmax fused into the GEMM epilogue (never stored)
-    int qkv_sub = 1;                          // > 1: in_proj + attention of a vision block run per sub-chunk of the launch sequence's images (run_block_f16)
     int fused_head = 1;                       // ovmr_fused_logits / ovmr_zeroshot_logits as ONE launch (head_fused.hip); 0: scale + GEMMs + softmax
     int head_max_grid = 0;                    // > 0 caps the fused head's grid (tests: workgroups then take several tiles)
     int* head_sync = nullptr;                 // the fused head's device counters (zero between launches)
@@ -212,20 +211,6 @@ int run_block_f16(ovmr_handle* h, const Block& k, half_t* x, half_t* y, half_t* 
     int M = nseq * L;
     if (groups) { M = 0; for (auto& g : *groups) M += g.nseq * g.L; }
     const int H = W / 64, slots = W / 256;
-    if (stats && !groups && h->qkv_sub > 1 && nseq >= 2 * h->qkv_sub) {
-        // in_proj + attention per SUB-CHUNK of the sequences (option "qkv_sub"): a sub-chunk's qkv rows (a third of 703 MB at 775 ViT-B/16
-        // images) are read back by attention while they still sit in the 256 MB memory-side cache, instead of after the whole launch
-        // sequence's in_proj has pushed them out to HBM.  Same kernels on row ranges: bit-identical results.
-        const int per = (nseq + h->qkv_sub - 1) / h->qkv_sub;
-        for (int n0 = 0; n0 < nseq; n0 += per) {
-            const int ns = std::min(per, nseq - n0);
-            const long r0 = (long)n0 * L;
-            CK(launch_gemm_f16(gemm_ln(gemm(x + r0 * W, W, k.in_wf, W, qkv + r0 * 3 * W, 3 * W, ns * L, 3 * W, W, EPI_LN_BIAS), stats + r0 * slots * 2, slots,
-                                       k.in_g, k.in_bf), h->gemm_variant, s));
-            CK(launch_attention_f16(qkv + r0 * 3 * W, y + r0 * W, ns, L, H, causal, h->attn_variant, s));
-        }
-        goto attention_done;
-    }
     if (stats) {
         CK(launch_gemm_f16(gemm_ln(gemm(x, W, k.in_wf, W, qkv, 3 * W, M, 3 * W, W, EPI_LN_BIAS), stats, slots, k.in_g, k.in_bf), h->gemm_variant, s));
     } else {
@@ -247,7 +232,6 @@ int run_block_f16(ovmr_handle* h, const Block& k, half_t* x, half_t* y, half_t* 
                 CK(launch_attention_f16(qkv + g.row0 * 3 * W, y + g.row0 * W, g.nseq, g.L, H, causal, h->attn_variant, s));
     } else
         CK(launch_attention_f16(qkv, y, nseq, L, H, causal, h->attn_variant, s));
-attention_done:
     CK(launch_gemm_f16(gemm_stats(gemm(y, W, k.out_w, W, x, W, M, W, W, EPI_BIAS_RES, k.out_b, x, W), stats), h->gemm_variant, s));
     if (stats) {
         CK(launch_gemm_f16(gemm_ln(gemm(x, W, k.fc_wf, W, hid, 4 * W, M, 4 * W, W, EPI_LN_BIAS_QGELU), stats, slots, k.fc_g, k.fc_bf), h->gemm_variant + (h->gelu_exact ? 0 : 100), s));
@@ -451,7 +435,6 @@ int ovmr_set_option(ovmr_handle* h, const char* key, int value) {
     else if (!strcmp(key, "ln_fold")) h->ln_fold = value;
     else if (!strcmp(key, "xval_fused")) h->xval_fused = value;
     else if (!strcmp(key, "fused_head")) h->fused_head = value;
-    else if (!strcmp(key, "qkv_sub")) h->qkv_sub = value < 1 ? 1 : value;
     else if (!strcmp(key, "head_max_grid")) h->head_max_grid = value;
     else if (!strcmp(key, "gelu_exact")) h->gelu_exact = value;
     else return fail(h, OVMR_E_NAME, "unknown option '%s'", key);
