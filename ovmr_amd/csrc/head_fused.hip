@@ -34,7 +34,8 @@ namespace {
 typedef float float16_t __attribute__((ext_vector_type(16)));
 
 constexpr int HF_BN = 128;                 // classes per tile: 4 waves x 32
-enum { HF_TICKET = 0, HF_DONE = 1, HF_LEFT_N = 2, HF_LEFT_POP = 3, HF_EXIT = 4, HF_SYNC_INTS = 16 };
+enum { HF_TICKET = 0, HF_DONE = 1, HF_LEFT_N = 2, HF_LEFT_POP = 3, HF_EXIT = 4, HF_DUTY_TICKET = 5, HF_DUTY_DONE = 6, HF_SYNC_INTS = 16 };
+constexpr int HF_LOCAL_MERGE_MAX = 16;     // class tiles up to which every workgroup merges its rows' per-tile statistics itself (C <= 2048)
 
 #ifdef OVMR_EXPERIMENTS
 // shader-clock stamps of workgroup 0 (tools/head_bench.py --stamps): where a launch spends its time
@@ -55,8 +56,8 @@ __global__ __launch_bounds__(256, 2) void head_fused_kernel(const half_t* __rest
                                                          const half_t* __restrict__ c0, const half_t* __restrict__ c1,
                                                          const half_t* __restrict__ c2, int n_mod, int C,
                                                          const float* __restrict__ w, float* __restrict__ out,
-                                                         half_t* __restrict__ raw_out, float* __restrict__ partial, int* __restrict__ leftover,
-                                                         int* sync, int Tc, int n_tiles) {
+                                                         half_t* __restrict__ raw_out, float* __restrict__ partial, float* __restrict__ merged,
+                                                         int* __restrict__ leftover, int* sync, int Tc, int n_tiles) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     constexpr int QB = BM / 32;                              // 32-query blocks per tile
     const int ldf = D + 8;                                   // LDS row stride in halves: + 16 B, so that the 16 lanes of a ds_read_b128 pass hit 64 distinct banks
@@ -230,6 +231,14 @@ __global__ __launch_bounds__(256, 2) void head_fused_kernel(const half_t* __rest
         auto emit = [&](int t) {
             const int tc = t % Tc, r0 = (t / Tc) * BM, cw0 = tc * HF_BN + wave * 32;
             __syncthreads();
+            if (Tc > HF_LOCAL_MERGE_MAX) {                        // merged once for everybody by the duty phase below
+                for (int i = tid; i < n_mod * BM; i += 256) {
+                    const int m = i / BM, q = i % BM;
+                    const float* p = merged + ((long)m * rows_pad + r0 + q) * 2;
+                    red[(m * BM + q) * 2] = aloadf(p);
+                    red[(m * BM + q) * 2 + 1] = aloadf(p + 1);
+                }
+            } else
             for (int i = tid; i < n_mod * BM; i += 256) {
                 const int m = i / BM, q = i % BM;
                 const float* p = partial + (((long)m * rows_pad + r0 + q) * Tc) * 2;
@@ -316,6 +325,50 @@ __global__ __launch_bounds__(256, 2) void head_fused_kernel(const half_t* __rest
             while (aload(sync + HF_DONE) < n_tiles) __builtin_amdgcn_s_sleep(2);
         __syncthreads();                                              // (the pairs are read with device-coherent loads: nothing to invalidate)
         HF_STAMP(5);
+        if (Tc > HF_LOCAL_MERGE_MAX) {
+            // Many class tiles: every workgroup of a row tile merging ALL of that row tile's pairs itself re-reads O(tiles^2) pairs
+            // (256 x 10 000: 74 us of uncached loads).  Instead the (row, classifier) statistics are merged ONCE: units of four of
+            // them (one per wave, the wave's lanes striding over the class tiles, then a fixed-order butterfly: deterministic) are
+            // handed out by a second ticket, and a second count of finished units orders the merged values before phase 2.
+            const int n_pairs = n_mod * rows_pad, n_units = (n_pairs + 3) / 4;
+            for (;;) {
+                __syncthreads();
+                if (tid == 0) sh_t = aadd(sync + HF_DUTY_TICKET, 1);
+                __syncthreads();
+                const int u = sh_t;
+                if (u >= n_units) break;
+                const int pr = u * 4 + wave;
+                if (pr < n_pairs) {
+                    const float* p = partial + (long)pr * Tc * 2;          // pair index = m * rows_pad + row: the layout of `partial`
+                    float M = -INFINITY, S = 0.f;
+                    for (int t = lane; t < Tc; t += 64) {
+                        const float mx = aloadf(p + 2 * t), sm = aloadf(p + 2 * t + 1);
+                        const float Mn = fmaxf(M, mx);
+                        if (Mn > -INFINITY) S = S * __expf(M - Mn) + sm * __expf(mx - Mn);
+                        M = Mn;
+                    }
+#pragma unroll
+                    for (int o = 1; o < 64; o <<= 1) {
+                        const float Mo = __shfl_xor(M, o, 64), So = __shfl_xor(S, o, 64);
+                        const float Mn = fmaxf(M, Mo);
+                        // (both partners compute the same sum: a + b with a, b swapped -- IEEE addition commutes, the lanes stay identical)
+                        const float a = Mn > -INFINITY ? S * __expf(M - Mn) : 0.f, b = Mn > -INFINITY ? So * __expf(Mo - Mn) : 0.f;
+                        S = (lane & o) ? b + a : a + b;
+                        M = Mn;
+                    }
+                    if (lane == 0) {
+                        astore(merged + (long)pr * 2, M);
+                        astore(merged + (long)pr * 2 + 1, 1.0f / S);
+                    }
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (tid == 0) aadd(sync + HF_DUTY_DONE, 1);
+            }
+            if (tid == 0)
+                while (aload(sync + HF_DUTY_DONE) < n_units) __builtin_amdgcn_s_sleep(2);
+            __syncthreads();
+        }
         HF_STAMP(6);
         // ---- phase 2
         if (held >= 0) emit(held);
@@ -336,7 +389,7 @@ __global__ __launch_bounds__(256, 2) void head_fused_kernel(const half_t* __rest
         // ---- the last workgroup to leave re-arms the counters for the next launch on this handle
         if (tid == 0 && aadd(sync + HF_EXIT, 1) == (int)gridDim.x - 1) {
 #pragma unroll
-            for (int i = 0; i < 5; ++i) __hip_atomic_store(sync + i, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int i = 0; i < 8; ++i) __hip_atomic_store(sync + i, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         HF_STAMP(8);
     }
@@ -344,7 +397,7 @@ __global__ __launch_bounds__(256, 2) void head_fused_kernel(const half_t* __rest
 
 template <int BM, bool RAW>
 int launch_one(const half_t* feats, int B, int D, float scale, const half_t* const* clf, int n_mod, int C, const float* w,
-               float* out, half_t* raw_out, float* partial, int* leftover, int* sync, int Tc, size_t lds, int max_grid, hipStream_t s) {
+               float* out, half_t* raw_out, float* partial, float* merged, int* leftover, int* sync, int Tc, size_t lds, int max_grid, hipStream_t s) {
     const int Tr = (B + BM - 1) / BM, n_tiles = Tr * Tc;
     auto kern = head_fused_kernel<BM, RAW>;
     static size_t lds_set = 0;                               // per instantiation: the largest dynamic LDS size granted so far
@@ -355,7 +408,7 @@ int launch_one(const half_t* feats, int B, int D, float scale, const half_t* con
     }
     const int grid = RAW ? n_tiles : std::max(1, std::min(n_tiles, max_grid > 0 ? max_grid : n_tiles));
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, s, feats, B, D, scale, clf[0], n_mod > 1 ? clf[1] : nullptr,
-                       n_mod > 2 ? clf[2] : nullptr, n_mod, C, w, out, raw_out, partial, leftover, sync, Tc, n_tiles);
+                       n_mod > 2 ? clf[2] : nullptr, n_mod, C, w, out, raw_out, partial, merged, leftover, sync, Tc, n_tiles);
     return (int)hipGetLastError();
 }
 
@@ -363,11 +416,11 @@ size_t head_lds_bytes(int BM, int D) { return (size_t)BM * (D + 8) * 2 + (size_t
 
 }  // namespace
 
-// Workspace the launch needs for B rows: floats [3][rows padded to 64][Tc][2] (tile pairs), then ints [rows / 32 x Tc] (the
-// recompute queue).
+// Workspace the launch needs for B rows: floats [3][rows padded to 64][Tc][2] (tile pairs), [3][rows][2] (merged), then ints
+// [rows / 32 x Tc] (the recompute queue).
 size_t head_fused_ws_bytes(int B, int C) {
     const size_t Tc = (C + HF_BN - 1) / HF_BN, rows = (size_t)(B + 63) / 64 * 64;
-    return 3 * rows * Tc * 2 * sizeof(float) + (rows / 32) * Tc * sizeof(int);
+    return 3 * rows * (Tc + 1) * 2 * sizeof(float) + (rows / 32) * Tc * sizeof(int);
 }
 int head_fused_sync_ints() { return HF_SYNC_INTS; }
 
@@ -387,11 +440,12 @@ int launch_head_fused(const half_t* feats, int B, int D, float scale, const half
     const size_t lds = head_lds_bytes(BM, D);
     const size_t rows = (size_t)(B + 63) / 64 * 64;
     float* partial = (float*)ws;
-    int* leftover = (int*)(partial + 3 * rows * Tc * 2);
-    if (raw) return BM == 32 ? launch_one<32, true>(feats, B, D, scale, clf, 1, C, nullptr, nullptr, raw_out, nullptr, nullptr, nullptr, Tc, lds, 0, s)
-                             : launch_one<64, true>(feats, B, D, scale, clf, 1, C, nullptr, nullptr, raw_out, nullptr, nullptr, nullptr, Tc, lds, 0, s);
-    return BM == 32 ? launch_one<32, false>(feats, B, D, scale, clf, n_mod, C, w, out, nullptr, partial, leftover, sync, Tc, lds, max_grid, s)
-                    : launch_one<64, false>(feats, B, D, scale, clf, n_mod, C, w, out, nullptr, partial, leftover, sync, Tc, lds, max_grid, s);
+    float* merged = partial + 3 * rows * Tc * 2;
+    int* leftover = (int*)(merged + 3 * rows * 2);
+    if (raw) return BM == 32 ? launch_one<32, true>(feats, B, D, scale, clf, 1, C, nullptr, nullptr, raw_out, nullptr, nullptr, nullptr, nullptr, Tc, lds, 0, s)
+                             : launch_one<64, true>(feats, B, D, scale, clf, 1, C, nullptr, nullptr, raw_out, nullptr, nullptr, nullptr, nullptr, Tc, lds, 0, s);
+    return BM == 32 ? launch_one<32, false>(feats, B, D, scale, clf, n_mod, C, w, out, nullptr, partial, merged, leftover, sync, Tc, lds, max_grid, s)
+                    : launch_one<64, false>(feats, B, D, scale, clf, n_mod, C, w, out, nullptr, partial, merged, leftover, sync, Tc, lds, max_grid, s);
 }
 
 #ifdef OVMR_EXPERIMENTS

@@ -417,7 +417,7 @@ def test_get_fusion_weight_coop_variant(golden, O):
 
 
 @pytest.mark.parametrize("model,D,cases", [
-    ("tiny", 128, ((6, 4, 5), (37, 3, 9), (1000, 4, 33), (130, 16, 256), (1003, 2, 70))),
+    ("tiny", 128, ((6, 4, 5), (37, 3, 9), (1000, 4, 33), (130, 16, 256), (1003, 2, 70), (2500, 2, 40))),   # 2500 classes = 20 class tiles: the head's duty-phase merge
     ("ViT-B/16", 512, ((1000, 16, 256),)),     # BASELINE config 3 exactly: 1000 classes x 16 shots, query batch 256, embed_dim 512
 ])
 def test_fusion_head_vs_oracle(O, model, D, cases):

@@ -10,7 +10,7 @@ import torch
 from ovmr_amd import synth
 from ovmr_amd.runtime import Engine
 
-for name, B, C in (("ViT-B/16", 256, 1000), ("ViT-B/16", 256, 10000), ("ViT-B/16", 64, 1000), ("ViT-B/16", 2048, 1000), ("ViT-L/14@336px", 128, 1000)):
+for name, B, C in (("ViT-B/16", 256, 1000), ("ViT-B/16", 256, 10000), ("ViT-B/16", 256, 21841), ("ViT-B/16", 512, 4096), ("ViT-B/16", 64, 1000), ("ViT-B/16", 2048, 1000), ("ViT-L/14@336px", 128, 1000)):
     spec = synth.SPECS[name]
     D = spec.embed_dim
     # only the head runs: an engine with no tower weights cannot be finalized, so build a tiny stand-in spec of the same embed_dim
