@@ -12,12 +12,15 @@
 //     classes per 32 x 32 tile: the row-wise softmax statistics are in-register maxima / sums plus one v_permlane32_swap (lanes
 //     l and l + 32 hold the same query) -- the layout of attention_v5.hip;
 //   * phase 1 leaves one (maximum, sum of exponentials) pair per (row, class tile, classifier) in a small workspace (device-coherent
-//     stores: no cache-wide write-back / invalidate); phase 2 merges the pairs of a row (online-softmax merge, in tile order:
-//     deterministic) and writes the weighted probabilities from the logits the workgroup STILL HOLDS IN REGISTERS.  Every workgroup
-//     of a row tile repeats that merge, so the pair traffic grows with the SQUARE of the class-tile count: the entry point takes
-//     this kernel up to 4096 classes and 512 rows and the five-launch path beyond (tools/head_bench.py: 256 x 1000 30 us against
-//     34, 64 x 1000 26 / 34, 128 x 1000 at width 768 35 / 39; 256 x 10 000 128 / 117, 2048 x 1000 62 / 56; letting the last tile
-//     of a row tile merge ONCE for all put that merge on the critical path and was slower everywhere).  Between them every tile must be done -- a device-wide dependency, built so that
+//     stores: no cache-wide write-back / invalidate); phase 2 merges the pairs of a row (online-softmax merge, fixed order:
+//     deterministic) and writes the weighted probabilities from the logits the workgroup STILL HOLDS IN REGISTERS.  Up to 16 class
+//     tiles (2048 classes) every workgroup merges its own rows' pairs; with more tiles that re-reads O(tiles^2) pairs per row tile
+//     (256 x 10 000: 74 us of uncached loads), so the merge becomes a phase of its own: units of four (row, classifier) statistics,
+//     one per wave with the lanes striding over the class tiles, handed out by a second ticket and counted like the tiles.
+//     tools/head_bench.py, device time per call: 256 x 1000 30 us against 34 for the five launches, 64 x 1000 26 / 34, 128 x 1000 at
+//     width 768 35 / 39, 256 x 10 000 101 / 117, 256 x 21 841 255 / 344; 512 x 4096 78 / 73 and 2048 x 1000 63 / 56 lose (each 64-row
+//     tile re-reads the classifier matrices), hence the entry point's rule: up to 256 rows, or up to 512 rows x 2048 classes.
+//   * Between them every tile must be done -- a device-wide dependency, built so that
 //     it cannot starve whatever else occupies the chip: tiles are handed out by an atomic ticket, so the workgroups that ARE
 //     resident work through all of them and wait on a count of finished TILES (not of arrived workgroups); a workgroup that took
 //     more than one tile keeps the last one in registers and queues the earlier ones for recomputation in phase 2 (normally the

@@ -850,10 +850,9 @@ int ovmr_fused_logits(ovmr_handle* h, const void* feats_f16, int B, const void* 
         default: return fail(h, OVMR_E_ARG, "unknown eval mode %d", mode);
     }
     for (int m = 0; m < n_mod; ++m) if (!clf[m]) return fail(h, OVMR_E_ARG, "classifier %d is NULL for mode %d", m, mode);
-    // (up to 512 query rows and 4096 classes: every 64-row tile re-reads the classifier matrices and every workgroup merges its
-    //  rows' per-tile statistics, so beyond that the GEMM path's 256-row tiles win -- tools/head_bench.py; option fused_head = 2
-    //  takes the one-launch kernel at any size)
-    if (h->fused_head && ((B <= 512 && C <= 4096) || h->fused_head == 2) && head_fused_ws_bytes(B, C) <= h->ws_bytes) {
+    // (up to 256 query rows at any class count, up to 512 rows x 2048 classes: every 64-row tile re-reads the classifier matrices, so
+    //  beyond that the GEMM path's 256-row tiles win -- tools/head_bench.py; option fused_head = 2 takes the one-launch kernel at any size)
+    if (h->fused_head && (B <= 256 || (B <= 512 && C <= 2048) || h->fused_head == 2) && head_fused_ws_bytes(B, C) <= h->ws_bytes) {
         // one launch: scaled features staged once, the (up to) three products, both rounding points, softmax and weighted sum (head_fused.hip)
         const half_t* cl[3] = {(const half_t*)clf[0], n_mod > 1 ? (const half_t*)clf[1] : nullptr, n_mod > 2 ? (const half_t*)clf[2] : nullptr};
         const int rc = launch_head_fused((const half_t*)feats_f16, B, D, h->logit_scale_exp, cl, n_mod, C, mode == OVMR_MODE_FUSION ? w : nullptr,
