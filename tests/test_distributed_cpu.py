@@ -148,9 +148,10 @@ def _free_port():
 
 
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize("world,C,presharded", [(2, 6, False), (4, 7, False), (4, 7, True)])
+@pytest.mark.parametrize("world,C,presharded", [(2, 6, False), (4, 7, False), (4, 7, True), (4, 3, True), (4, 3, False)])
 def test_multi_rank_generation_matches_single_process(world, C, presharded):
-    """2 ranks x 6 classes; 4 ranks x 7 classes (ragged: shards of 2, 2, 2, 1), round-robin batches and class-sharded loader."""
+    """2 ranks x 6 classes; 4 ranks x 7 classes (ragged: shards of 2, 2, 2, 1), round-robin batches and class-sharded loader;
+    4 ranks x 3 classes: a rank that owns NO class still takes part in both collectives (an empty block, zero votes)."""
     with tempfile.TemporaryDirectory() as d:
         r1, r2 = os.path.join(d, "single.pt"), os.path.join(d, "dist.pt")
         _run(0, 1, 0, os.path.join(d, "o1"), r1, C, False)
