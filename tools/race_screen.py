@@ -102,6 +102,43 @@ for rep in range(a.reps):
         mism += 1
 bad += mism
 print(f"image tower, small model, 300 images: {a.reps} encodes, {mism} differ from the first", flush=True)
+# (round 5: the one-launch classifier head -- tiles by ticket, device-coherent per-tile statistics, a count of finished tiles, above 16 class
+#  tiles a second ticketed merge phase, self re-arming counters -- alone, with its grid capped (workgroups take several tiles: the recompute
+#  queue), and from TWO handles on two streams at once (the test loop's two batches in flight))
+from ovmr_amd.runtime import Engine
+tiny = synth.ModelSpec("head", 512, 32, 1, 128, 16, 77, 1000, 512, 8, 1)
+engines = []
+for _ in range(2):
+    en = Engine(tiny, 2)
+    en.load_state_dict({k: torch.from_numpy(v) for k, v in synth.clip_state_dict(tiny, 1).items()},
+                       {k: torch.from_numpy(v) for k, v in synth.prompt_learner_state_dict(tiny, 2, 1).items()})
+    en.finalize(64, 64, 22000)
+    en.set_option("fused_head", 2)
+    engines.append(en)
+streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+for (B, C, cap) in ((256, 1000, 0), (256, 10000, 0), (37, 1003, 0), (256, 1000, 5), (256, 10000, 100), (512, 21841, 0)):
+    g = torch.Generator(device="cuda").manual_seed(B + C)
+    f = torch.nn.functional.normalize(torch.randn((B, 512), generator=g, device="cuda"), dim=-1).half()
+    clf = [torch.nn.functional.normalize(torch.randn((C, 512), generator=g, device="cuda"), dim=-1).half() for _ in range(3)]
+    w = torch.softmax(torch.randn((C, 3), generator=g, device="cuda"), -1)
+    for en in engines:
+        en.set_option("head_max_grid", cap)
+    ref, mism, reps = None, 0, max(20, a.reps // 2)
+    torch.cuda.synchronize()
+    for rep in range(reps):
+        if rep % 3 == 0:
+            junk.add_(1.0)
+        torch.cuda.synchronize()
+        outs = []
+        for en, st in zip(engines, streams):                      # the two handles' launches overlap on the device
+            with torch.cuda.stream(st):
+                outs.append(en.fused_logits(f, *clf, w, "fusion"))
+        torch.cuda.synchronize()
+        if ref is None:
+            ref = outs[0].clone()
+        mism += sum(0 if torch.equal(o, ref) else 1 for o in outs)
+    bad += mism
+    print(f"one-launch head {(B, C)} grid cap {cap}: {reps} x 2 concurrent launches, {mism} differ from the first", flush=True)
 torch.cuda.synchronize()
 print("RACE SCREEN", "CLEAN" if bad == 0 else f"FAILED ({bad} differing launches)")
 sys.exit(1 if bad else 0)
