@@ -77,7 +77,8 @@ def parse(argv=None):
     ap.add_argument("--enc-chunk", type=int, default=0, help="images per launch sequence of the image tower: 0 = the engine's choice (<= --batch, whole "
                     "rounds of tiles: ovmr_encode_chunk), n pins it")
     ap.add_argument("--overlap", type=int, default=-1, help="two query batches in flight on two streams (CustomCLIP.forward_batches): "
-                    "1 / 0 force it on / off, -1 = the module's rule (batches of at most 384 images)")
+                    "1 / 0 force it on / off, -1 = the module's rule (batches of at most 384 images); 2 / 3: the reference's unchanged test loop "
+                    "instead -- model(input) per batch + a host sync per batch -- with forward() splitting a batch over two handles (2) or not (3)")
     ap.add_argument("--classes-per-batch", type=int, default=DEFAULT_CLASSES_PER_BATCH,
                     help="classes per eval-set loader batch: the whole 1000-class exemplar set arrives as one batch, the engine encodes it "
                          "--batch images at a time and the classifier head runs once (r03y: 775 / 1000 against 768 / 240: +1.5-2 % end to end)")
@@ -192,7 +193,7 @@ def main():
     loader = ResidentEvalSet(ex_img, torch.arange(c0, c1, device=dev), S, args.classes_per_batch, presharded=True)
 
     infer_only = PRESETS[args.preset].get("value") == "inference"    # c3: the classifiers are set-up, the step is the query loop
-    if args.overlap == 1 or (args.overlap < 0 and args.query_batch <= model.OVERLAP_MAX_BATCH):
+    if args.overlap in (1, 2) or (args.overlap < 0 and args.query_batch <= model.OVERLAP_MAX_BATCH):
         model._twin()                                   # set-up, like the first handle's: the second handle forward_batches uses (not part of a step)
 
     def generate():
@@ -209,6 +210,14 @@ def main():
         if not infer_only:
             generate()
         outs = None
+        if args.overlap >= 2:
+            # the reference's UNCHANGED test loop (Dassl.pytorch/dassl/engine/trainer.py:461-482): one model(input) per batch and the
+            # evaluator's host round trip per batch; 2: forward() runs the batch's two halves on two handles, 3: one handle
+            model.SPLIT_FORWARD = args.overlap == 2
+            for b in query_batches():
+                outs = model(b)
+                int(outs.max(1)[1].sum().item())
+            return outs
         for outs in model.forward_batches(query_batches(), stable_inputs=True, overlap=None if args.overlap < 0 else bool(args.overlap)):
             pass                                         # (the reference's loop hands each batch's logits to the evaluator)
         return outs
@@ -244,8 +253,12 @@ def main():
     barrier()
     tg = time.perf_counter(); model.forward_prompt(loader); torch.cuda.synchronize(); tg = time.perf_counter() - tg
     ti = time.perf_counter()
-    for _ in model.forward_batches(query_batches(), stable_inputs=True, overlap=None if args.overlap < 0 else bool(args.overlap)):
-        pass
+    if args.overlap >= 2:
+        for b in query_batches():
+            int(model(b).max(1)[1].sum().item())
+    else:
+        for _ in model.forward_batches(query_batches(), stable_inputs=True, overlap=None if args.overlap < 0 else bool(args.overlap)):
+            pass
     torch.cuda.synchronize(); ti = time.perf_counter() - ti
 
     images_per_step = Q if infer_only else C * S + Q

@@ -484,17 +484,46 @@ class CustomCLIP:
                                       "pass eval_set_loader= to generate the classifiers")
         if self.mm_classifier is None:                                              # :341-342 (the features of `image` do not depend on it)
             self.forward_prompt(eval_set_loader)
+        if self.SPLIT_FORWARD and 2 * self.SPLIT_MIN_HALF <= image.shape[0] <= self._split_cap():
+            return self._forward_split(image)
         return self._forward_on(self.engine, image)
 
     __call__ = forward
 
-    def _forward_on(self, engine: Engine, image):
+    def _forward_on(self, engine: Engine, image, out=None):
         image_features = engine.encode_image(image, normalize=True)                # :305-307
         mode = self.cfg.EVAL_MODE
         if mode not in ("text", "vision", "multimodal", "fusion"):
             raise ValueError(f"unknown EVAL_MODE {mode}")
         return engine.fused_logits(image_features, self.mm_classifier, self.visual_classifer,
-                                   self.zero_shot_classifier, self.fusion_weight, mode)
+                                   self.zero_shot_classifier, self.fusion_weight, mode, out=out)
+
+    # ------------------------------------------------------------------ one forward, its two halves in flight
+    SPLIT_FORWARD = True          # forward(image) of an UNCHANGED test loop (one model(input) per batch, a host sync per batch): the batch's
+    SPLIT_MIN_HALF = 64           # two halves run on two handles / streams, so that the partial last round of GEMM tiles of one half is filled
+                                  # by the other's work -- what forward_batches does across batches, without asking the caller for the next batch.
+                                  # Same rows bit for bit (a row's arithmetic does not depend on its batch: tests/test_hip_configs.py).
+
+    def _split_cap(self) -> int:
+        return min(self.OVERLAP_MAX_BATCH, 2 * getattr(self.engine, "_reserve", (256,))[0])
+
+    def _forward_split(self, image):
+        image = self.engine._dev(image)
+        B, C = image.shape[0], len(self.tokenized_prompts)
+        half = (B + 1) // 2
+        cur = torch.cuda.current_stream(self.device)
+        if not hasattr(self, "_split_stream"):
+            self._split_stream = torch.cuda.Stream(self.device)
+        st, twin = self._split_stream, self._twin()
+        out = torch.empty((B, C), dtype=torch.float32, device=self.device)
+        st.wait_stream(cur)                                  # the image (and `out`) exist for the side stream
+        with torch.cuda.stream(st):
+            self._forward_on(twin, image[half:], out=out[half:])
+        self._forward_on(self.engine, image[:half], out=out[:half])
+        cur.wait_stream(st)
+        image.record_stream(st)
+        out.record_stream(st)
+        return out
 
     # ------------------------------------------------------------------ the test loop's forwards, two batches in flight
     OVERLAP_MAX_TILES = 1024      # two batches in flight while the narrowest GEMM grid of ONE batch (ceil(rows / 256) x width / 256

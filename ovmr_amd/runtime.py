@@ -330,12 +330,14 @@ class Engine:
                  "ovmr_fusion_weights")
         return out
 
-    def fused_logits(self, feats, mm, v, t, w, mode: str = "fusion") -> torch.Tensor:
+    def fused_logits(self, feats, mm, v, t, w, mode: str = "fusion", out: Optional[torch.Tensor] = None) -> torch.Tensor:
         feats = self._dev(feats, torch.float16)
         cl = [None if x is None else self._dev(x, torch.float16) for x in (mm, v, t)]
         w = None if w is None else self._dev(w, torch.float32)
         C = next(x.shape[0] for x in cl if x is not None)
-        out = torch.empty((feats.shape[0], C), dtype=torch.float32, device=self.device)
+        if out is None:
+            out = torch.empty((feats.shape[0], C), dtype=torch.float32, device=self.device)
+        assert out.shape == (feats.shape[0], C) and out.dtype == torch.float32 and out.is_contiguous()
         self._ck(self.lib.ovmr_fused_logits(self.h, _ptr(feats), feats.shape[0], _ptr(cl[0]), _ptr(cl[1]), _ptr(cl[2]),
                                             _ptr(w), C, MODES[mode], _ptr(out), _stream()), "ovmr_fused_logits")
         return out

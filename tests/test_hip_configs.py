@@ -410,6 +410,18 @@ def test_forward_batches_equals_forward_with_two_batches_in_flight(tmp_path):
     it.close()
     assert torch.equal(first, want[0]) and torch.equal(model(chunks[3]), want[3]) and torch.equal(model(chunks[0]), want[0])
 
+    # forward() itself splits a batch of at least 2 x SPLIT_MIN_HALF images over the two handles: the same rows, bit for bit, as one handle
+    model.SPLIT_MIN_HALF = 6                                                   # 2 x 6 <= 24 <= 32 (the twin's capacity): split
+    split = model(q[:24])
+    assert hasattr(model, "_split_stream") and split.shape == (24, C)
+    assert torch.equal(split, want[0])                                         # (want[0] was one handle: 24 < 2 x 64)
+    assert torch.equal(split, torch.cat([model._forward_on(model.engine, q[:12]), model._forward_on(model.engine, q[12:24])]))
+    odd = model(q[:23])                                                        # halves of 12 and 11 rows
+    assert torch.equal(odd, want[0][:23])
+    model.SPLIT_FORWARD = False
+    assert torch.equal(model(q[:24]), want[0])
+    model.SPLIT_FORWARD = True
+    model.SPLIT_MIN_HALF = 64
     model.engine.set_option("gelu_exact", 1)                                   # the twin mirrors the options of the first handle ...
     want_exact = [model(c).clone() for c in chunks[:3]]
     got = [o.clone() for o in model.forward_batches(iter(chunks[:3]))]
