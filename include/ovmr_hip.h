@@ -62,7 +62,7 @@ void ovmr_destroy(ovmr_handle* h);
 const char* ovmr_last_error(const ovmr_handle* h);
 const char* ovmr_version(void);
 
-/* Kernel-variant switch used by tests/bench to A/B implementations: key in {"gemm","attn","ln_fold","xval_fused","gelu_exact","fuse_im2col","enc_chunk","last_q_cls"}.
+/* Kernel-variant switch used by tests/bench to A/B implementations: key in {"gemm","attn","ln_fold","xval_fused","gelu_exact","fuse_im2col","enc_chunk","last_q_cls","fused_head","head_max_grid"}.
  * "gemm" (default 8): 8 = 256-row LDS-DMA tiles with the ping-pong K loop (half-tile staging, counted waits) and, for latency-bound shapes
  *   (at most one round -- 256 -- of 64 x 64 tiles: the text tower on a few dozen prompts, CLS-row chains), the 64 x 64 kernel that splits K
  *   over its waves; 7 = 8 without that kernel (A/B); 6 = the 256-row tiles with the double-buffered K loop; 9 = the 64 x 64 split-K kernel wherever it takes the shape (tests);
@@ -78,11 +78,17 @@ const char* ovmr_version(void);
  * "gelu_exact" (default 0): QuickGELU of the c_fc epilogue (clip/model.py:162-164).  1 keeps the three fp16 rounding points of the
  *   reference's fp16 tensors (h(1.702 u), h(sigmoid), h(u s)); 0 evaluates x / (1 + exp(-1.702 x)) in fp32 on the unrounded
  *   linear output and rounds once -- closer to the real function, within a few fp16 steps of the reference's value, and 5 % off
- *   the c_fc launch (DESIGN.md section 5).
+ *   the c_fc launch (DESIGN.md section 2).
  * "fuse_im2col" (default 1): conv1 on fp16 images with 16 x 16 patches -- the patch-embedding GEMM gathers its A rows from the image
  *   tensor inside its K loop; 0 writes the patch matrix out first (what fp32 images and other patch sizes always do).  Bit-identical.
  * "last_q_cls" (default 1): the last vision block (whose output is read at the CLS row only, clip/model.py:423) projects K and V for every
- *   token and Q for the CLS rows alone when a launch sequence holds at least 256 images; 0 projects Q for every token.  Bit-identical. */
+ *   token and Q for the CLS rows alone when a launch sequence holds at least 256 images; 0 projects Q for every token.  Bit-identical.
+ * "fused_head" (default 1): ovmr_fused_logits / ovmr_zeroshot_logits as ONE launch (csrc/head_fused.hip: scaled features staged once, the up
+ *   to three products on the matrix pipe, both fp16 rounding points of trainers/mm_classifier_one_prompt.py:357-363, softmax and weighted
+ *   sum) for up to 256 query rows, or up to 512 rows x 2048 classes; larger calls run scale + GEMMs + softmax as separate launches.
+ *   2 = one launch at any size; 0 = never.  The two implementations sum K in different orders: a logit may land on the neighbouring fp16
+ *   value (tests/test_hip_parity.py:test_fusion_head_vs_oracle holds both to the oracle).
+ * "head_max_grid" (default 0 = one workgroup per tile): caps the one-launch head's grid (tests: workgroups then take several tiles). */
 int ovmr_set_option(ovmr_handle* h, const char* key, int value);
 
 /* Weight ingestion -- replaces build_model()/convert_weights()/load_state_dict
