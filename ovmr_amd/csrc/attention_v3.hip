@@ -23,6 +23,7 @@
 #include "attn_single_pass.h"
 
 #include <algorithm>
+#include <cstdlib>
 
 namespace {
 
@@ -32,13 +33,18 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 // hipcc then does not know an LDS write is in flight.  With the builtin it put an `s_waitcnt vmcnt(0)` in front of the first
 // transposing V read of every head -- i.e. it waited for the NEXT head's whole K / V stream before the PV products, which is the
 // overlap this kernel exists for.  Ordering is by hand: counted wait + barrier at the top of the head loop.
+template <bool STREAM>
 __device__ __forceinline__ void glds16_asm(const void* gsrc, unsigned lds_dst) {
     unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+    if constexpr (STREAM)      // (experiment build: K / V with the nontemporal policy, so that they do not evict the attention output from the caches)
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+    else
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 }
 
-template <int NT>                                      // key sub-tiles of 16: (NT - 1) * 16 < L <= NT * 16
+template <int NT, bool STREAM = false>                 // key sub-tiles of 16: (NT - 1) * 16 < L <= NT * 16
 __global__ __launch_bounds__(896, 4) void attn_f16_v3(const half_t* __restrict__ qkv, half_t* __restrict__ out,
                                                       int L, int H, int nBH, float scale_log2e) {
     constexpr int ROWS = NT * 16, NW = 14, NS = (NT + 1) / 2;    // NS: PV steps of 32 keys
@@ -60,7 +66,7 @@ __global__ __launch_bounds__(896, 4) void attn_f16_v3(const half_t* __restrict__
             const int isv = ins >= 2 * NT, r0 = (isv ? ins - 2 * NT : ins) * 8;
             const int kc = min(r0 + srow, L - 1);              // rows past the last key repeat it: finite values, masked below
             const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + 2u * (unsigned)(buf * HEAD + isv * (ROWS * 64) + r0 * 64));
-            glds16_asm(base + (1 + isv) * D + (long)kc * ld + schunk, dst);
+            glds16_asm<STREAM>(base + (1 + isv) * D + (long)kc * ld + schunk, dst);
         }
     };
     auto load_q = [&](const half_t* base, half8_t (&q)[2]) {
@@ -122,6 +128,18 @@ int launch_attention_f16_v3(const half_t* qkv, half_t* out, int B, int L, int Lq
     const float sl2e = 0.125f * 1.4426950408889634f;
     const int nBH = B * H;
     const int grid = std::min(nBH, std::max(1, n_cu[dev]));     // persistent: one 14-wave workgroup per CU walks the heads
+#ifdef OVMR_EXPERIMENTS
+    static const bool stream_kv = getenv("OVMR_ATTN3_NT") && atoi(getenv("OVMR_ATTN3_NT"));
+    if (stream_kv) {
+        static bool set2[OVMR_MAX_DEVICES] = {};
+        if (!set2[dev]) {
+            HIP_CHECK_RET(hipFuncSetAttribute((const void*)attn_f16_v3<NT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            set2[dev] = true;
+        }
+        hipLaunchKernelGGL((attn_f16_v3<NT, true>), dim3((unsigned)grid), dim3(896), lds, s, qkv, out, L, H, nBH, sl2e);
+        return (int)hipGetLastError();
+    }
+#endif
     hipLaunchKernelGGL((attn_f16_v3<NT>), dim3((unsigned)grid), dim3(896), lds, s, qkv, out, L, H, nBH, sl2e);
     return (int)hipGetLastError();
 }
