@@ -141,3 +141,29 @@ def test_pipelined_loader_resizes_on_the_device_and_keeps_its_pool(tmp_path):
         assert torch.equal(a["img"].half(), b["img"].cpu())
     loader.close_pools()
     assert not loader._POOLS
+
+
+def test_resize_crop_u8_edges():
+    """n = 0 is a no-op; NULL pointers / non-positive sizes come back as OVMR_E_ARG (no launch); an already R x R frame passes through
+    PIL's identity (both passes skipped there, unit weights here) unchanged; pass-through jobs are copied."""
+    import ctypes
+    from ovmr_amd import loader, runtime
+    lib = runtime.load_library()
+    z = ctypes.c_void_p(0)
+    assert lib.ovmr_resize_crop_u8(z, z, 0, z, z, 0, z, 224, z) == 0
+    buf = torch.zeros(1024, dtype=torch.uint8, device="cuda")
+    p = ctypes.c_void_p(buf.data_ptr())
+    assert lib.ovmr_resize_crop_u8(z, p, 1, p, p, 1, p, 224, z) != 0           # no pixels
+    assert lib.ovmr_resize_crop_u8(p, p, 1, p, p, 1, p, 0, z) != 0             # R = 0
+    assert lib.ovmr_resize_crop_u8(p, p, 1, p, z, 5, p, 224, z) != 0           # an intermediate is needed but not given
+    rng = np.random.default_rng(3)
+    same = rng.integers(0, 256, (64, 64, 3), dtype=np.uint8)
+    got = loader.resize_crop_u8([same], 64).cpu().numpy()[0]
+    assert np.array_equal(got, same)
+    # pass-through: the arena already holds the crop
+    r = loader.DeviceResizer(64, "bicubic")
+    arena = torch.from_numpy(same.reshape(-1).copy()).cuda()
+    out = torch.empty((1, 64, 64, 3), dtype=torch.uint8, device="cuda")
+    r.run(arena, [(0, 64, 64, 1)], out, torch.cuda.current_stream())
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy()[0], same)
