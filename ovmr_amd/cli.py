@@ -281,6 +281,22 @@ def main(argv=None) -> Dict[str, float]:
     from .evaluator import Classification
     from .tokenizer import BPETokenizer
 
+    # launched by torch.distributed.run (scripts/generate_classifier.sh with several GPUs): one rank per GPU, process group nccl = RCCL;
+    # forward_prompt then shards the classes over the ranks (two collectives) and rank 0 evaluates and writes
+    import torch.distributed as dist
+    own_group = False
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1 and not dist.is_initialized():
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+        backend = os.environ.get("OVMR_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            args.device = f"cuda:{local}"
+        torch.cuda.set_device(torch.device(args.device))
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device(args.device))
+        else:
+            dist.init_process_group(backend)
+        own_group = True
     if seed >= 0:
         print(f"Setting fixed seed: {seed}")                  # train.py:157-159
         torch.manual_seed(seed)
@@ -326,6 +342,11 @@ def main(argv=None) -> Dict[str, float]:
                                prompt_learner_state=pl_state, reserve=(batch, 256, max(1024, len(classnames))))
     evaluator = Classification(len(classnames), classnames, device=args.device)
     model.forward_prompt(eval_loader)        # the reference does this inside the first forward (:341-342); up front it keeps the two loaders' statistics apart
+    if rank > 0:                             # the classifiers are complete on every rank; rank 0 evaluates the test set and reports
+        if own_group:
+            dist.barrier()
+            dist.destroy_process_group()
+        return {}
     labels = collections.deque()
 
     def test_images():
@@ -344,6 +365,9 @@ def main(argv=None) -> Dict[str, float]:
                   f"host blocked on decode {st['decode_wait_s']:.2f} s = {100 * st['decode_bound_fraction']:.0f} % of the time")
             results[f"pipeline_{name.split()[0]}"] = st
     results["classnames"] = classnames
+    if own_group:
+        dist.barrier()
+        dist.destroy_process_group()
     return results
 
 

@@ -4,6 +4,7 @@
 Bar (BASELINE.json north_star): 1 - cosine <= 1e-3 for classifier rows, features and per-image
 outputs in fp16.  Needs an MI355X: `pytest -m gpu`."""
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -652,6 +653,24 @@ def test_cli_generate_and_evaluate_end_to_end(tmp_path, O):
     for k in ("text_classifier", "vision_classifier", "mm_classifier"):
         assert_cosine(saved[k].numpy(), r[k].numpy(), COS_TOL, k)
     assert cli.main(common + ["--output-dir", str(out)]) == {}          # "results exist ... skip this job"
+    # the same command line under torch.distributed.run (what scripts/generate_classifier.sh does for several GPUs): two ranks, here over
+    # gloo on the test box's one GPU -- the runner opens the process group itself, the classes are sharded over the ranks, rank 0 evaluates
+    # and writes; the classifier files must equal the one-process run's bit for bit
+    import subprocess
+    out2 = tmp_path / "out_2ranks"
+    env = dict(os.environ, OVMR_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0",
+               PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))) + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    r2 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                         "--master-port", "29533", "-m", "ovmr_amd.cli"] + common +
+                        ["--output-dir", str(out2), "--workers", "2", "DATASET.NUM_SHOTS", str(S), "DATASET.SUBSAMPLE_CLASSES", "all"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r2.returncode == 0, r2.stdout[-2000:] + r2.stderr[-3000:]
+    saved2 = torch.load(out2 / "mm_classifiers.pt", map_location="cpu")
+    for k in ("text_classifier", "vision_classifier", "mm_classifier", "fusion_weight"):
+        assert torch.equal(saved2[k], saved[k]), f"{k}: two ranks differ from one process"
+    assert torch.equal(torch.load(out2 / "visual_tokens.pt", map_location="cpu")["visual_tokens"],
+                       torch.load(out / "visual_tokens.pt", map_location="cpu")["visual_tokens"])
+    assert (out2 / "acc_per_class.csv").exists()
     # DATASET.SUBSAMPLE_CLASSES new: the second half of the classes (datasets/oxford_pets.py:141-202), relabelled from 0 -- a
     # 2-row classifier file whose rows are the all-classes job's rows 2 and 3 (same exemplars: the draw precedes the subsampling)
     out_new = tmp_path / "out_new"
