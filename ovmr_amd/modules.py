@@ -495,8 +495,9 @@ class CustomCLIP:
         mode = self.cfg.EVAL_MODE
         if mode not in ("text", "vision", "multimodal", "fusion"):
             raise ValueError(f"unknown EVAL_MODE {mode}")
+        kw = {} if out is None else {"out": out}             # (only the split forward hands an output slice in)
         return engine.fused_logits(image_features, self.mm_classifier, self.visual_classifer,
-                                   self.zero_shot_classifier, self.fusion_weight, mode, out=out)
+                                   self.zero_shot_classifier, self.fusion_weight, mode, **kw)
 
     # ------------------------------------------------------------------ one forward, its two halves in flight
     SPLIT_FORWARD = True          # forward(image) of an UNCHANGED test loop (one model(input) per batch, a host sync per batch): the batch's
