@@ -67,3 +67,26 @@ def aligned_case(g, name, tag="l2a", seed=11, n_ctx=None):
     qlab = g[f"{tag}_query_labels"]
     q = synth.images(len(qlab), spec.image_resolution, seed=777, class_ids=qlab, class_strength=s, tile=tile)
     return spec, sd, pl, labels, img, qlab, q
+
+
+def usable_threads(cap=32):
+    """Threads the CPU oracle may use without oversubscribing: the affinity mask capped by the cgroup CPU quota (the GPU boxes report 256
+    hardware threads but grant 16 CPUs: a 32-thread pool there runs slower than a 16-thread one), at most `cap`."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, per = f.read().split()
+            if q != "max":
+                n = min(n, max(1, int(float(q) / float(per))))
+    except Exception:                                      # noqa: BLE001 -- cgroup v1 / no cgroup: the affinity mask stands
+        pass
+    return max(1, min(cap, n))
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _oracle_thread_pool():
+    """The CPU oracle's intra-op pool: torch's default is one thread per HARDWARE thread of the host (256 on the GPU boxes, whose cgroup
+    grants 16 CPUs) -- an oversubscribed pool is several times slower.  Tests that want fewer set their own."""
+    import torch
+    torch.set_num_threads(usable_threads())
+    yield

@@ -15,7 +15,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import COS_TOL, assert_cosine, near_tie_classes
+from conftest import usable_threads, COS_TOL, assert_cosine, near_tie_classes
 from ovmr_amd import synth
 
 pytestmark = pytest.mark.gpu
@@ -98,7 +98,7 @@ def test_headline_config_bench_job_vs_oracle(O):
     cpu_sd = O.convert_weights({k: x.detach().float().cpu() for k, x in sd.items()}, "fp16")
     cpu_pl = {k: x.detach().float().cpu() for k, x in pl.items()}
     sample = [0, 333, 642, 999]
-    torch.set_num_threads(min(32, os.cpu_count()))
+    torch.set_num_threads(usable_threads())
     rows = torch.cat([ex[c * S:(c + 1) * S] for c in sample]).cpu()
     with torch.no_grad():
         r = O.forward_prompt(rows, torch.arange(len(sample)).repeat_interleave(S), tok[sample], cpu_sd, cpu_pl, n_ctx, 10.0,
@@ -257,7 +257,7 @@ def test_config_c4_vitb16_sixty_four_shots_one_rank_of_eight(O):
     first = torch.randn((1024, 3, R, R), generator=ig, device=dev).half()
     sample = [0, 629, c5]
     rows = torch.cat([ex0[0:S], ex0[629 * S:630 * S], first[:S]]).cpu()
-    torch.set_num_threads(min(32, os.cpu_count()))
+    torch.set_num_threads(usable_threads())
     with torch.no_grad():
         r = O.forward_prompt(rows, torch.arange(3).repeat_interleave(S), tok[sample], cpu_sd, cpu_pl, 2, 10.0, 3, "fp16")
         qf = O.l2_normalize(O.encode_image(keep["queries"][:8].cpu(), cpu_sd))

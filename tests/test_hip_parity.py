@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import COS_TOL, aligned_case, assert_cosine, cosine_rows, near_tie_classes
+from conftest import usable_threads, COS_TOL, aligned_case, assert_cosine, cosine_rows, near_tie_classes
 from ovmr_amd import synth
 
 pytestmark = pytest.mark.gpu
@@ -709,7 +709,7 @@ def aligned_job(O, spec, C, S, gain, strength, tile, pool=0, n_ctx=2, seed=SEED)
             pattern[(i + 1) * S - m:(i + 1) * S] = (int(c) + 1) % C
     img = synth.images(C * S, spec.image_resolution, seed=1234, class_ids=pattern, class_strength=strength, tile=tile)
     sd = O.convert_weights(O.to_torch(sd_np), "fp16")
-    torch.set_num_threads(min(32, os.cpu_count()))
+    torch.set_num_threads(usable_threads())
     with torch.no_grad():
         f = torch.cat([O.l2_normalize(O.encode_image(torch.from_numpy(img[s:s + 32]).half(), sd)) for s in range(0, C * S, 32)])
     if pool:
@@ -856,7 +856,7 @@ def test_other_clip_backbones_vs_oracle(O, name, n_img):
     f = e.encode_image(img, normalize=True).float().cpu()
     t = e.encode_text_ids(ids, normalize=1).float().cpu()
     sd = O.convert_weights(O.to_torch(sd_np), "fp16")
-    torch.set_num_threads(min(32, os.cpu_count()))
+    torch.set_num_threads(usable_threads())
     k = min(n_img, 4)
     with torch.no_grad():
         rf = O.l2_normalize(O.encode_image(img[:k].half(), sd)).float()
@@ -888,7 +888,7 @@ def test_config_c5_vit_l14_336_encode(O):
     f = e.encode_image(img, normalize=True).float().cpu()
     t = e.encode_text_ids(ids, normalize=1).float().cpu()
     sd = O.convert_weights(O.to_torch(sd_np), "fp16")
-    torch.set_num_threads(min(32, os.cpu_count()))
+    torch.set_num_threads(usable_threads())
     with torch.no_grad():
         rf = O.l2_normalize(O.encode_image(img.half(), sd)).float()
         rt = O.l2_normalize(O.encode_text(ids, sd)).float()
@@ -975,7 +975,7 @@ def test_config_c5_vit_l14_336_thirty_two_shots(O, tmp_path):
     model = modules.CustomCLIP(cfg, tok, cm, prompt_learner_state={k: torch.from_numpy(v) for k, v in pl_np.items()}, reserve=(64, 8, 8))
     mm, v, fw = model.forward_prompt([{"img": img, "label": torch.from_numpy(labels)}])
     sd = O.convert_weights(O.to_torch(sd_np), "fp16")
-    torch.set_num_threads(min(32, os.cpu_count()))
+    torch.set_num_threads(usable_threads())
     with torch.no_grad():
         r = O.forward_prompt(img, torch.from_numpy(labels), tok, sd, O.to_torch(pl_np), 2, tau, C, "fp16")
     assert model.visual_tokens.shape == (C, 2, 768)
