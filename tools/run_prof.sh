@@ -22,6 +22,9 @@ OVMR_DIST_BACKEND=gloo timeout 900 python -m torch.distributed.run --nnodes=1 --
 timeout 600 python tools/head_bench.py > profiles/${T}_head_bench.log 2>&1
 timeout 600 python tools/attn_bench.py --variants 1 3 > profiles/${T}_attn_bench.log 2>&1
 bash tools/pmc_attn_l577.sh gpurun_out/${T}_pmc_attn_l577 > gpurun_out/${T}_pmc_attn_l577.log 2>&1; cp gpurun_out/${T}_pmc_attn_l577/summary.json profiles/${T}_pmc_attn_l577.json
+bash tools/pmc_head.sh gpurun_out/${T}_pmc_head > profiles/${T}_pmc_head.log 2>&1; cp gpurun_out/${T}_pmc_head/summary.json profiles/${T}_pmc_head.json; rm -rf gpurun_out/${T}_pmc_head/*/
+timeout 900 python tools/race_screen.py --reps 200 > profiles/${T}_race_screen.log 2>&1
+timeout 600 python tools/resize_sweep.py > profiles/${T}_resize_sweep.log 2>&1
 timeout 900 python tools/pipeline_bench.py --workers 16 --host-resize > gpurun_out/${T}_pipeline.log 2>&1; grep -E "^input pipeline|usable" gpurun_out/${T}_pipeline.log > profiles/${T}_pipeline_bench.log
 cd /tmp; export TMPDIR=/tmp
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${T}_stats -- python3 $R/bench.py --steps 3 --warmup 1 --cpu-sample-classes 0 --presets 0 > $R/gpurun_out/${T}_stats_bench.log 2>&1
