@@ -7,6 +7,7 @@
 # (output_ovmr/generated_classifiers, skipped when it exists), same files in it (mm_classifiers.pt, visual_tokens.pt).  What this path
 # needs in addition, from the environment: CLIP_WEIGHTS (OpenAI CLIP .pt: there is no download here) and OVMR_BPE_PATH (default:
 # $OVMR_REF/clip/bpe_simple_vocab_16e6.txt.gz).  DATA, MODEL_DIR, CFG, SHOTS, LOADEP, WORKERS may be overridden the same way.
+# DRY_RUN=1 prints the command line instead of running it.
 # GPU_ID selects the device with HIP_VISIBLE_DEVICES; a comma-separated list starts one rank per GPU (torch.distributed.run, RCCL):
 # the classes are sharded over the ranks.
 set -e
@@ -37,7 +38,10 @@ ARGS=(--root "$DATA" --seed "$SEED" --trainer $TRAINER
       --eval_mode "$EVAL_MODE" --eval_tau "$EVAL_TAU" --n_ctx "$N_CTX" --eval-only
       --clip-weights "$CLIP_WEIGHTS" ${WORKERS:+--workers "$WORKERS"}
       DATASET.NUM_SHOTS "$SHOTS" DATASET.SUBSAMPLE_CLASSES "$SUB")
-if [ -d "$DIR" ]; then
+if [ -n "$DRY_RUN" ]; then                     # print the command instead of running it (tests/test_next_rows_cpu.py)
+    [ "$N" -gt 1 ] && echo "ranks $N"
+    printf '%s\n' python -m ovmr_amd.cli "${ARGS[@]}"
+elif [ -d "$DIR" ]; then
     echo "Oops! The results exist at ${DIR} (so skip this job)"
 elif [ "$N" -gt 1 ]; then
     python -m torch.distributed.run --nnodes=1 --nproc-per-node "$N" --master-addr 127.0.0.1 --master-port "${MASTER_PORT:-29531}" \

@@ -455,3 +455,33 @@ def test_resize_tables_reproduce_pil_bit_for_bit():
     assert resize.resized_size(500, 375, 224) == (298, 224) and resize.resized_size(375, 500, 224) == (224, 298)
     with pytest.raises(ValueError):
         resize.plan(10, 10, 224, "nearest")
+
+
+def test_generate_classifier_script_maps_the_reference_arguments(tmp_path):
+    """scripts/generate_classifier.sh takes the reference script's seven positional arguments (scripts/mm_cls/generate_classifier.sh:2-8)
+    and builds the reference's command line (:30-44) for `python -m ovmr_amd.cli`, which `cli.parse` + `config.setup_cfg` accept."""
+    import subprocess
+    from ovmr_amd import cli
+    script = os.path.join(REPO, "scripts", "generate_classifier.sh")
+    env = dict(os.environ, DRY_RUN="1", CLIP_WEIGHTS="/w/ViT-B-16.pt", OVMR_REF="/ref", DIR=str(tmp_path / "out"))
+    r = subprocess.run(["bash", script, "imagenet", "1", "all", "2", "fusion", "10", "0"], env=env, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    words = r.stdout.split("\n")[:-1]
+    assert words[:3] == ["python", "-m", "ovmr_amd.cli"]
+    argv = words[3:]
+    flat = " ".join(argv)
+    for piece in ("--root ./data", "--seed 1", "--trainer MM_CLS_OP", "--dataset-config-file /ref/configs/datasets/imagenet.yaml",
+                  "--config-file /ref/configs/trainers/MM_CLS_OP/vit_b16_c4_ep50_imagenet21k_pretrain.yaml", "--model-dir ./checkpoints",
+                  "--load-epoch 30", "--eval_mode fusion", "--eval_tau 10", "--n_ctx 2", "--eval-only", "--clip-weights /w/ViT-B-16.pt",
+                  "DATASET.NUM_SHOTS 16", "DATASET.SUBSAMPLE_CLASSES all"):
+        assert piece in flat, piece
+    a = cli.parse(argv)
+    assert a.eval_only and a.trainer == "MM_CLS_OP" and a.load_epoch == 30 and a.n_ctx == 2 and a.eval_mode == "fusion" and a.eval_tau == 10
+    assert a.opts == ["DATASET.NUM_SHOTS", "16", "DATASET.SUBSAMPLE_CLASSES", "all"]
+    r = subprocess.run(["bash", script, "imagenet", "1", "new", "2", "fusion", "10", "0,1,2,3"], env=env, capture_output=True, text=True)
+    assert r.returncode == 0 and r.stdout.startswith("ranks 4") and "DATASET.SUBSAMPLE_CLASSES\nnew" in r.stdout
+    r = subprocess.run(["bash", script, "imagenet", "1"], env=env, capture_output=True, text=True)
+    assert r.returncode == 2 and "usage" in r.stderr
+    env.pop("CLIP_WEIGHTS")
+    r = subprocess.run(["bash", script, "imagenet", "1", "all", "2", "fusion", "10", "0"], env=env, capture_output=True, text=True)
+    assert r.returncode != 0 and "CLIP_WEIGHTS" in r.stderr
