@@ -403,11 +403,15 @@ int launch_one(const half_t* feats, int B, int D, float scale, const half_t* con
                float* out, half_t* raw_out, float* partial, float* merged, int* leftover, int* sync, int Tc, size_t lds, int max_grid, hipStream_t s) {
     const int Tr = (B + BM - 1) / BM, n_tiles = Tr * Tc;
     auto kern = head_fused_kernel<BM, RAW>;
-    static size_t lds_set = 0;                               // per instantiation: the largest dynamic LDS size granted so far
-    if (lds > 64 * 1024 && lds > lds_set) {
-        const hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
-        lds_set = lds;
+    static size_t lds_set[OVMR_MAX_DEVICES] = {};            // per instantiation and device: the largest dynamic LDS size granted so far
+    if (lds > 64 * 1024) {
+        int dev = 0;
+        HIP_CHECK_RET(hipGetDevice(&dev));
+        if (dev < 0 || dev >= OVMR_MAX_DEVICES) return -100;
+        if (lds > lds_set[dev]) {
+            HIP_CHECK_RET(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            lds_set[dev] = lds;
+        }
     }
     const int grid = RAW ? n_tiles : std::max(1, std::min(n_tiles, max_grid > 0 ? max_grid : n_tiles));
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, s, feats, B, D, scale, clf[0], n_mod > 1 ? clf[1] : nullptr,
