@@ -291,12 +291,15 @@ def get_fusion_weight_coop(eval_feats: Tensor, mm: Tensor, v: Tensor, t: Tensor,
 
 def forward_prompt(images_by_class: Tensor, labels: Tensor, tokenized_prompts: Tensor,
                    sd: Dict[str, Tensor], pl: Dict[str, Tensor], n_ctx: int, tau: float,
-                   classes_per_batch: int, prec: str = "fp16", text_classifier: Optional[Tensor] = None):
+                   classes_per_batch: int, prec: str = "fp16", text_classifier: Optional[Tensor] = None,
+                   image_features: Optional[Tensor] = None):
     """CustomCLIP.forward_prompt, trainers/mm_classifier_one_prompt.py:214-292 (hot loop A + K18-K20).
 
     images_by_class [C*S,3,R,R] with S consecutive rows per class, labels [C*S] (batch contract
     of Dassl's RandomClassSampler).  Returns a dict with the tensors the
     reference writes to mm_classifiers.pt / visual_tokens.pt plus eval_feat4cls.
+    image_features [C*S, D]: l2_normalize(encode_image(images)) of THIS oracle, computed by the caller beforehand (a test that already
+    ran the tower over the same images does not run it twice: ViT-L on a CPU takes a second per image); None = encode here.
     """
     dt = torch.float16 if prec == "fp16" else torch.float32
     C = tokenized_prompts.shape[0]
@@ -319,7 +322,10 @@ def forward_prompt(images_by_class: Tensor, labels: Tensor, tokenized_prompts: T
         ncls = img.shape[0] // S                                         # :237
         ex_label = lab.reshape(ncls, S)[:, 0]                            # :240
         tok = tokenized_prompts[ex_label]                                # :241
-        f = l2_normalize(encode_image(img.to(dt), sd)).reshape(ncls, S, -1)   # :243-245
+        if image_features is None:
+            f = l2_normalize(encode_image(img.to(dt), sd)).reshape(ncls, S, -1)   # :243-245
+        else:
+            f = image_features[s0:s0 + step].to(dt).reshape(ncls, S, -1)
         eval_feats[ex_label] = f                                         # :247
         mm_p, mm_l, v_p, v_l, tokens = prompt_learner_forward(
             f, ex_label, tok.argmax(dim=-1), prompt_tokens, vtemp, pl, n_ctx)      # :248

@@ -739,8 +739,8 @@ def test_config_c2_vit_b16_hundred_classes_eight_shots(golden, O):
     g = golden("vitb16")
     spec, C, S, tau = synth.SPECS["ViT-B/16"], 100, 8, 3.0
     # gain searched on the CPU oracle: 1.5 (the 12-class fixture's) leaves 86 classes free of near-ties, 2.5 leaves 95 (mm rows: 19 near-tied)
-    sd_np, pl_np, sd, labels, pattern, img, tok, _ = aligned_job(O, spec, C, S, 2.5, float(g["l2a_meta_strength"]),
-                                                                 int(g["l2a_meta_tile"]), pool=600)
+    sd_np, pl_np, sd, labels, pattern, img, tok, feats_oracle = aligned_job(O, spec, C, S, 2.5, float(g["l2a_meta_strength"]),
+                                                                            int(g["l2a_meta_tile"]), pool=600)
     cm = modules.CLIPModel({k: torch.from_numpy(v) for k, v in sd_np.items()}, spec)
     cfg = modules.make_cfg(n_ctx=2, num_shots=S, eval_tau=tau, output_dir="", test_batch_size=768)
     model = modules.CustomCLIP(cfg, tok, cm, prompt_learner_state={k: torch.from_numpy(v) for k, v in pl_np.items()},
@@ -751,7 +751,7 @@ def test_config_c2_vit_b16_hundred_classes_eight_shots(golden, O):
     q = torch.from_numpy(synth.images(8, spec.image_resolution, 777, qlab, float(g["l2a_meta_strength"]), tile=int(g["l2a_meta_tile"])))
     out = model(q, eval_set_loader=loader).cpu()
     with torch.no_grad():
-        r = O.forward_prompt(timg, tlab, tok, sd, O.to_torch(pl_np), 2, tau, 96, "fp16")
+        r = O.forward_prompt(timg, tlab, tok, sd, O.to_torch(pl_np), 2, tau, 96, "fp16", image_features=feats_oracle)   # (aligned_job ran the tower)
         qf = O.l2_normalize(O.encode_image(q.half(), sd))
     assert_cosine(model.eval_feat4cls.flatten(0, 1).float().cpu().numpy(), r["eval_feat4cls"].flatten(0, 1).float().numpy(), COS_TOL, "eval_feat4cls")
     for name, got, ref in (("mm", model.mm_classifier, r["mm_classifier"]), ("vision", model.visual_classifer, r["vision_classifier"]),
@@ -914,8 +914,8 @@ def test_config_c5_vit_l14_336_generation_end_to_end(O, tmp_path):
     from ovmr_amd import modules
     spec = synth.SPECS["ViT-L/14@336px"]
     C, S, tau = C5_JOB["C"], C5_JOB["S"], 3.0
-    sd_np, pl_np, sd, labels, pattern, img_np, tok, _ = aligned_job(O, spec, C, S, C5_JOB["gain"], C5_JOB["strength"], C5_JOB["tile"],
-                                                                    pool=C5_JOB["pool"])
+    sd_np, pl_np, sd, labels, pattern, img_np, tok, feats_oracle = aligned_job(O, spec, C, S, C5_JOB["gain"], C5_JOB["strength"], C5_JOB["tile"],
+                                                                               pool=C5_JOB["pool"])
     cm = modules.CLIPModel({k: torch.from_numpy(v) for k, v in sd_np.items()}, spec)
     cfg = modules.make_cfg(n_ctx=2, num_shots=S, eval_tau=tau, output_dir=str(tmp_path), size=336)
     model = modules.CustomCLIP(cfg, tok, cm, prompt_learner_state={k: torch.from_numpy(v) for k, v in pl_np.items()}, reserve=(C * S, 3 * C, C))
@@ -928,7 +928,7 @@ def test_config_c5_vit_l14_336_generation_end_to_end(O, tmp_path):
         outs[mode] = model(q, eval_set_loader=loader).cpu()
         assert outs[mode].shape == (2, C) and outs[mode].dtype == torch.float32
     with torch.no_grad():
-        r = O.forward_prompt(img, torch.from_numpy(labels), tok, sd, O.to_torch(pl_np), 2, tau, C, "fp16")
+        r = O.forward_prompt(img, torch.from_numpy(labels), tok, sd, O.to_torch(pl_np), 2, tau, C, "fp16", image_features=feats_oracle)
         qf = O.l2_normalize(O.encode_image(q.half(), sd))
     assert_cosine(model.eval_feat4cls.float().cpu().flatten(0, 1).numpy(), r["eval_feat4cls"].float().flatten(0, 1).numpy(), COS_TOL, "eval_feat4cls")
     assert_cosine(model.visual_tokens.float().cpu().flatten(0, 1).numpy(), r["visual_tokens"].float().flatten(0, 1).numpy(), COS_TOL, "visual tokens")
