@@ -123,8 +123,31 @@ def parse(argv=None):
     return args
 
 
+def preflight(args):
+    """Before anything touches the GPU.  (1) The environment every multi-process GPU test of this repo runs under (tests/test_hip_distributed.py,
+    tests/test_hip_parity.py, scripts/generate_classifier.sh): HSA_ENABLE_IPC_MODE_LEGACY=0 -- the host driver of this pool supports only dmabuf
+    IPC, and with the legacy mode RCCL's (and torch's) cross-process buffer sharing fails with `hipIpcGetMemHandle: invalid argument`.  The image
+    exports it already; setdefault keeps an operator's explicit choice and makes `bench.py --gpus N` independent of the login shell.
+    (2) One device per rank: `--gpus N` over RCCL needs N visible devices.  device_count() does not initialise the GPU, so a launcher that
+    fails here has started nothing; the error is ONE line and the exit code 2 (no retry, no re-exec)."""
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    world = int(os.environ.get("WORLD_SIZE", str(args.gpus)))
+    if world > 1 and os.environ.get("OVMR_DIST_BACKEND", "nccl") == "nccl":
+        import torch
+        n = torch.cuda.device_count()
+        if n < world:
+            if int(os.environ.get("RANK", "0")) == 0:
+                print(f"bench.py: --gpus {world} over RCCL needs {world} visible devices, this node shows {n} "
+                      f"(HIP_VISIBLE_DEVICES={os.environ.get('HIP_VISIBLE_DEVICES', '<unset>')}); OVMR_DIST_BACKEND=gloo lets ranks share a device",
+                      file=sys.stderr, flush=True)
+            sys.exit(2)
+    if "WORLD_SIZE" in os.environ and args.gpus != world and int(os.environ.get("RANK", "0")) == 0:
+        print(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s); the launcher's count is used", file=sys.stderr, flush=True)
+
+
 def main():
     args = parse()
+    preflight(args)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # launched by hand with --gpus N: start one process per GPU as a child, before touching the GPU
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
@@ -200,7 +223,7 @@ def main():
         if not sharded and not args.stream_text:
             model.zero_shot_classifier = model.prompt_learner.zero_shot_classifier = \
                 model.prompt_learner.encode_zero_shot(model.tokenized_prompts)     # part of the job (:118-126)
-        model.forward_prompt(loader)
+        model.forward_prompt(loader, wait_files=False)   # rank 0's two files are written by a worker thread while the queries run; step() joins it
 
     def query_batches():                                 # the test loader: resident images, --query-batch at a time
         for b in range(0, q_img.shape[0], args.query_batch):
@@ -217,9 +240,10 @@ def main():
             for b in query_batches():
                 outs = model(b)
                 int(outs.max(1)[1].sum().item())
-            return outs
-        for outs in model.forward_batches(query_batches(), stable_inputs=True, overlap=None if args.overlap < 0 else bool(args.overlap)):
-            pass                                         # (the reference's loop hands each batch's logits to the evaluator)
+        else:
+            for outs in model.forward_batches(query_batches(), stable_inputs=True, overlap=None if args.overlap < 0 else bool(args.overlap)):
+                pass                                     # (the reference's loop hands each batch's logits to the evaluator)
+        model.wait_files()                               # both files complete on disk INSIDE the step
         return outs
 
     if infer_only:
@@ -251,7 +275,8 @@ def main():
 
     # phase split (untimed extra pass, informational)
     barrier()
-    tg = time.perf_counter(); model.forward_prompt(loader); torch.cuda.synchronize(); tg = time.perf_counter() - tg
+    tg = time.perf_counter(); model.forward_prompt(loader, wait_files=False); torch.cuda.synchronize(); tg = time.perf_counter() - tg
+    tf = time.perf_counter(); model.wait_files(); tf = time.perf_counter() - tf    # what is left of the file write once the GPU is idle (in a step it overlaps the queries)
     ti = time.perf_counter()
     if args.overlap >= 2:
         for b in query_batches():
@@ -278,6 +303,7 @@ def main():
         # one SCALE line shows the skew between ranks: every rank's own time per step (its steps done, before the closing barrier) and
         # its phase split, gathered over the group itself (host objects: any backend)
         mine = {"rank": rank, "ms_per_step_own": round(1000 * dt_own, 3), "generation_ms": round(1000 * tg, 3), "inference_ms": round(1000 * ti, 3),
+                "files_join_ms": round(1000 * tf, 3),
                 "classes": c1 - c0, "query_images": q1 - q0}
         per_rank = [None] * world
         dist.all_gather_object(per_rank, mine)
@@ -309,6 +335,9 @@ def main():
             "roofline": roof,
             "cpu_baseline": cpu,
             "phases": {"generation_images_per_s_rank0": round((c1 - c0) * S / tg, 1),
+                       "generation_ms_rank0": round(1000 * tg, 3),
+                       "files_join_ms_after_generation_alone": round(1000 * tf, 3) if out_dir else None,
+                       "files_written_by": "a worker thread behind a side stream (CustomCLIP._write_files), joined at the end of every step",
                        "inference_images_per_s_rank0": round((q1 - q0) / ti, 1) if q1 > q0 else None,
                        "inference_query_batch": args.query_batch,
                        "inference_batches_in_flight": 2 if (args.overlap == 1 or (args.overlap < 0 and args.query_batch <= model.OVERLAP_MAX_BATCH)) else 1,
@@ -557,8 +586,10 @@ def emulate_world(args, model, spec, dev):
         if not args.stream_text:
             model.zero_shot_classifier = model.prompt_learner.zero_shot_classifier = \
                 model.prompt_learner.encode_zero_shot(model.tokenized_prompts)
-        model.forward_prompt(full_loader)
-        return queries(q_all, collect)
+        model.forward_prompt(full_loader, wait_files=False)
+        out = queries(q_all, collect)
+        model.wait_files()
+        return out
 
     t1 = timed(whole)
     ref = {k: getattr(model, k).clone() for k in ("mm_classifier", "visual_classifer", "zero_shot_classifier", "fusion_weight", "visual_tokens")}
@@ -586,15 +617,18 @@ def emulate_world(args, model, spec, dev):
         model._dist, model._text_streamed = emu, True
 
         def shard_step(collect=False):
-            model.forward_prompt(loader)
-            return queries(q, collect)
+            model.forward_prompt(loader, wait_files=False)     # (rank 0 writes the files: off its critical path, joined at the end of the step)
+            out = queries(q, collect)
+            model.wait_files()
+            return out
 
         shard_step()                                        # records this rank's own votes
         emu.peer_counts = counts_full - emu.local_counts
         tr = timed(shard_step)
         out = shard_step(collect=True)
         torch.cuda.synchronize()
-        tg = time.perf_counter(); model.forward_prompt(loader); torch.cuda.synchronize(); tg = time.perf_counter() - tg
+        tg = time.perf_counter(); model.forward_prompt(loader, wait_files=False); torch.cuda.synchronize(); tg = time.perf_counter() - tg
+        model.wait_files()
         # this rank's OWN rows against the whole job's rows for the same classes (the other ranks' rows are the recorded ones): equal
         # bits where the shard and the whole job take the same kernels, 1 - cos ~1e-6 apart where the smaller head takes others
         own = torch.arange(c0, c1, device=dev)
@@ -693,8 +727,10 @@ def shard_of_world(args, model, spec, dev, keep=None):
         return torch.cat(outs) if collect and outs else out
 
     def step():
-        model.forward_prompt(loader)
-        return queries()
+        model.forward_prompt(loader, wait_files=False)
+        out = queries()
+        model.wait_files()
+        return out
 
     step()                                                   # records this rank's own votes (EmulatedPeers.all_reduce)
     emu.peer_counts = counts_full - emu.local_counts
@@ -708,7 +744,8 @@ def shard_of_world(args, model, spec, dev, keep=None):
     dt = (time.perf_counter() - t0) / args.steps
 
     # phase split and the cross-validation step alone (untimed extra passes)
-    tg = time.perf_counter(); model.forward_prompt(loader); torch.cuda.synchronize(); tg = time.perf_counter() - tg
+    tg = time.perf_counter(); model.forward_prompt(loader, wait_files=False); torch.cuda.synchronize(); tg = time.perf_counter() - tg
+    model.wait_files()
     ti = time.perf_counter(); out = queries(collect=True); torch.cuda.synchronize(); ti = time.perf_counter() - ti
     own = torch.arange(c0, c1, device=dev)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

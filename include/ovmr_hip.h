@@ -187,6 +187,15 @@ int ovmr_fused_logits(ovmr_handle* h, const void* feats_f16, int B, const void* 
 int ovmr_zeroshot_logits(ovmr_handle* h, const void* feats_f16, int B, const void* text_f16, int C,
                          void* out_f16, ovmr_stream stream);
 
+/* Classification.process of the test loop (Dassl.pytorch/dassl/evaluation/evaluator.py:50-67): outputs [B, C] (fp32 = what
+ * CustomCLIP.forward returns, or fp16 = ZeroshotCLIP's raw logits; row stride ld elements), labels int64 [B] (the batch's LongTensor as
+ * it is).  pred = outputs.max(1)[1] -- lowest column on ties, a NaN is the largest value -- then counts[0][pred] += (pred == label)
+ * (true positives), counts[1][pred] += 1, counts[2][label] += 1; counts is int32 [3][C] followed by ONE more int32 that counts the rows
+ * whose label lies outside [0, C) (such rows touch no histogram; the host raises when it is not zero).  The caller zeroes counts once
+ * and accumulates over the batches of a test pass: no host round trip per batch (the reference does .item() / .cpu() per batch, :59-67);
+ * accuracy, error rate, macro-F1 and the per-class tables of evaluate() (:69-138) are functions of these 3C integers.  Needs no handle. */
+int ovmr_eval_counts(const void* outputs, int dtype, long ld, const int64_t* labels, int B, int C, int32_t* counts, ovmr_stream stream);
+
 /* exp(logit_scale) as held by the handle (set through ovmr_set_weight("logit_scale")). */
 float ovmr_logit_scale(const ovmr_handle* h);
 

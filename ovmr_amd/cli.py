@@ -341,7 +341,9 @@ def main(argv=None) -> Dict[str, float]:
     model = modules.CustomCLIP(cfg, classnames, clip_model, tokenizer=BPETokenizer(args.bpe_path),
                                prompt_learner_state=pl_state, reserve=(batch, 256, max(1024, len(classnames))))
     evaluator = Classification(len(classnames), classnames, device=args.device)
-    model.forward_prompt(eval_loader)        # the reference does this inside the first forward (:341-342); up front it keeps the two loaders' statistics apart
+    # the reference does this inside the first forward (:341-342); up front it keeps the two loaders' statistics apart.  Rank 0's two
+    # files are written by a worker thread while the test set runs (CustomCLIP._write_files), joined below
+    model.forward_prompt(eval_loader, wait_files=False)
     if rank > 0:                             # the classifiers are complete on every rank; rank 0 evaluates the test set and reports
         if own_group:
             dist.barrier()
@@ -356,6 +358,7 @@ def main(argv=None) -> Dict[str, float]:
 
     for out in model.forward_batches(test_images(), eval_set_loader=eval_loader):      # two test batches in flight (modules.py)
         evaluator.process(out, labels.popleft())
+    model.wait_files()
     results = dict(evaluator.evaluate(out_dir))
     for name, ld in (("exemplar set", eval_loader), ("test set", test_loader)):
         st = getattr(ld, "stats", None)

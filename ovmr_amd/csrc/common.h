@@ -184,6 +184,7 @@ int launch_assemble_prompts(const half_t* base, const int64_t* labels, const flo
 int launch_argmax_counts(const half_t* logits, int ld, const int* labels, int R, int C, int* tp, int* n_pred, hipStream_t s);
 int launch_argmax_reduce(const float* partial, int tiles, const int* labels, int R, int C, int* tp, int* n_pred, hipStream_t s);
 int launch_fusion_weights(const int* counts, const int* n_label, int C, float tau, float* out, hipStream_t s);
+int launch_eval_counts(const void* out, int out_is_f32, long ld, const int64_t* labels, int B, int C, int* counts, hipStream_t s);
 int launch_scale_f16(const half_t* x, half_t* y, float scale, long n, hipStream_t s);
 struct ovmr_resize_job;
 int launch_resize_crop_u8(const uint8_t* pixels, const ovmr_resize_job* jobs, int n, const int32_t* tables, uint8_t* tmp, int max_ny,

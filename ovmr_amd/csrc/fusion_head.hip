@@ -74,6 +74,74 @@ __global__ __launch_bounds__(256) void xval_argmax_reduce(const float* __restric
     wave_histogram_add(tp, bi, ok && bi == labels[live ? row : 0]);
 }
 
+// Classification.process of the test loop (Dassl.pytorch/dassl/evaluation/evaluator.py:50-67): pred = mo.max(1)[1] (lowest column on ties;
+// a NaN counts as the largest value, the first one wins -- torch's rule), then the three histograms every figure of evaluate() is
+// made of (:69-138: accuracy = sum tp / total, per-class accuracy = tp / n_label, F1 from tp, n_pred, n_label).  One wave per output row
+// (16-byte loads where the row is aligned), the block's rows are counted by its first wave with one atomic per distinct class.
+// counts = int32 [3][C] (tp, n_pred, n_label) + [1]: rows whose label lies outside [0, C) (counted nowhere else).
+template <typename T>
+__device__ __forceinline__ void eval_row_argmax(const T* __restrict__ row, int C, int lane, float& best, int& bi) {
+    best = -INFINITY;
+    bi = 0x7fffffff;
+    auto take = [&](float v, int c) {
+        // strict >: the first (lowest) column of a value wins inside a lane; NaN beats everything that is not NaN
+        if (bi == 0x7fffffff || v > best || (v != v && best == best)) { best = v; bi = c; }
+    };
+    constexpr int V = 16 / (int)sizeof(T);
+    if ((((uintptr_t)row) & 15) == 0) {
+        const int Cv = C / V * V;
+        for (int c = lane * V; c < Cv; c += 64 * V) {
+            if constexpr (sizeof(T) == 4) {
+                const float4 q = *(const float4*)(row + c);
+                take(q.x, c); take(q.y, c + 1); take(q.z, c + 2); take(q.w, c + 3);
+            } else {
+                const uint4 q = *(const uint4*)(row + c);
+                const unsigned u[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    half2_t h2 = *(const half2_t*)&u[i];
+                    take((float)h2[0], c + 2 * i); take((float)h2[1], c + 2 * i + 1);
+                }
+            }
+        }
+        for (int c = Cv + lane; c < C; c += 64) take((float)row[c], c);
+    } else
+        for (int c = lane; c < C; c += 64) take((float)row[c], c);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(best, o, 64);
+        const int oi = __shfl_xor(bi, o, 64);
+        const bool on = ov != ov, bn = best != best;
+        const bool better = oi != 0x7fffffff && (bi == 0x7fffffff || (on && !bn) || (!bn && ov > best) || ((ov == best || (on && bn)) && oi < bi));
+        if (better) { best = ov; bi = oi; }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void eval_counts_kernel(const T* __restrict__ out, long ld, const int64_t* __restrict__ labels,
+                                                          int rows, int C, int* __restrict__ counts) {
+    __shared__ int pred_s[4], gt_s[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int row = blockIdx.x * 4 + wave;
+    float best;
+    int bi = 0x7fffffff;
+    if (row < rows) eval_row_argmax(out + (long)row * ld, C, lane, best, bi);
+    if (lane == 0) {
+        pred_s[wave] = row < rows ? bi : -1;
+        const int64_t g = row < rows ? labels[row] : -1;
+        gt_s[wave] = row < rows ? ((g >= 0 && g < C) ? (int)g : -2) : -1;
+    }
+    __syncthreads();
+    if (wave == 0) {
+        const int p = lane < 4 ? pred_s[lane] : -1, g = lane < 4 ? gt_s[lane] : -1;
+        const bool live = g >= 0 && p >= 0 && p < C;
+        wave_histogram_add(counts + 2 * C, g, live);                  // n_label
+        wave_histogram_add(counts + C, p, live);                      // n_pred
+        wave_histogram_add(counts, p, live && p == g);                // tp
+        wave_histogram_add(counts + 3 * C, 0, g == -2);               // labels outside [0, C)
+    }
+}
+
 // counts: int32 [3][2][C] = {mm, vision, text} x {tp, n_pred}; n_label: int32 [C]
 __global__ void fusion_weights_kernel(const int* __restrict__ counts, const int* __restrict__ n_label, int C,
                                       float tau, float* __restrict__ out) {
@@ -146,6 +214,15 @@ int launch_argmax_counts(const half_t* logits, int ld, const int* labels, int R,
 int launch_argmax_reduce(const float* partial, int tiles, const int* labels, int R, int C, int* tp, int* n_pred, hipStream_t s) {
     if (R <= 0) return 0;
     hipLaunchKernelGGL(xval_argmax_reduce, dim3((R + 255) / 256), dim3(256), 0, s, partial, tiles, labels, R, C, tp, n_pred);
+    return (int)hipGetLastError();
+}
+
+int launch_eval_counts(const void* out, int out_is_f32, long ld, const int64_t* labels, int B, int C, int* counts, hipStream_t s) {
+    if (B <= 0) return 0;
+    if (out_is_f32)
+        hipLaunchKernelGGL(eval_counts_kernel<float>, dim3((B + 3) / 4), dim3(256), 0, s, (const float*)out, ld, labels, B, C, counts);
+    else
+        hipLaunchKernelGGL(eval_counts_kernel<half_t>, dim3((B + 3) / 4), dim3(256), 0, s, (const half_t*)out, ld, labels, B, C, counts);
     return (int)hipGetLastError();
 }
 

@@ -833,6 +833,12 @@ int ovmr_fusion_weights(ovmr_handle* h, const int32_t* counts, const int32_t* n_
     return 0;
 }
 
+int ovmr_eval_counts(const void* outputs, int dtype, long ld, const int64_t* labels, int B, int C, int32_t* counts, ovmr_stream stream) {
+    if (B == 0) return 0;
+    if (!outputs || !labels || !counts || B < 0 || C < 1 || ld < C || (dtype != OVMR_F16 && dtype != OVMR_F32)) return OVMR_E_ARG;
+    return launch_eval_counts(outputs, dtype == OVMR_F32, ld, labels, B, C, counts, (hipStream_t)stream);
+}
+
 int ovmr_fused_logits(ovmr_handle* h, const void* feats_f16, int B, const void* mm, const void* v, const void* t,
                       const float* w, int C, int mode, float* out_f32, ovmr_stream stream) {
     if (h && B == 0) return 0;

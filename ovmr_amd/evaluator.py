@@ -1,8 +1,14 @@
 """On-device classification evaluator.
 
 Arithmetic of Dassl's `Classification` evaluator (Dassl.pytorch/dassl/evaluation/evaluator.py:50-138): top-1 accuracy,
-error rate, macro-F1 and per-class accuracy / F1, but accumulated as three int64 histograms on the GPU -- the reference
-does `.item()` and `.cpu().numpy()` per batch (:59-67), i.e. one host sync per batch of 256 images.
+error rate, macro-F1 and per-class accuracy / F1, accumulated as three histograms on the GPU by ONE launch per batch of
+the library's own row-argmax-and-count kernel (`ovmr_eval_counts`, csrc/fusion_head.hip: the cross-validation step's
+counting, on the [B, C] outputs) -- the reference does `.item()` and `.cpu().numpy()` per batch (:59-67), i.e. one host
+sync per batch of 256 images; here the host reads 3C + 1 integers once, in evaluate().
+
+Outputs that live on the GPU go through the kernel and nothing else: without libovmr_hip.so `process` raises.  Host
+tensors (an evaluator built with device="cpu": host-side callers, the CPU tests of evaluate()'s arithmetic) are counted
+on the host.
 """
 from __future__ import annotations
 
@@ -21,21 +27,57 @@ class Classification:
         self.reset()
 
     def reset(self):
-        z = lambda: torch.zeros(self.num_classes, dtype=torch.int64, device=self.device)
-        self._tp, self._n_pred, self._n_label = z(), z(), z()
+        # int32 [3][C] = tp, n_pred, n_label, + one slot counting rows whose label is outside [0, C) (include/ovmr_hip.h: ovmr_eval_counts)
+        self._counts = torch.zeros(3 * self.num_classes + 1, dtype=torch.int32, device=self.device)
 
     @torch.no_grad()
     def process(self, mo: torch.Tensor, gt: torch.Tensor):
-        """mo: [B, C] model output, gt: [B] labels (evaluator.py:50-67).  No host synchronisation."""
-        pred = mo.argmax(dim=1)                                          # mo.max(1)[1]
-        gt = gt.to(pred.device).long()
+        """mo: [B, C] model output (fp32 probabilities of CustomCLIP.forward, or fp16 zero-shot logits), gt: [B] labels
+        (evaluator.py:50-67).  One kernel launch on the current stream, no host synchronisation."""
         C = self.num_classes
-        self._n_label += torch.bincount(gt, minlength=C)
-        self._n_pred += torch.bincount(pred, minlength=C)
-        self._tp += torch.bincount(gt[pred == gt], minlength=C)
+        if mo.dim() != 2 or mo.shape[1] != C or gt.shape[0] != mo.shape[0]:
+            raise ValueError(f"outputs {tuple(mo.shape)} / labels {tuple(gt.shape)} do not fit {C} classes")
+        if self.device.type == "cpu":
+            self._process_host(mo, gt)
+            return
+        from . import runtime
+        lib = runtime.load_library()                                      # raises without the HIP library: no fallback for device tensors
+        mo = mo.to(self.device)
+        if mo.dtype not in (torch.float16, torch.float32):
+            mo = mo.float()
+        if mo.stride(1) != 1:
+            mo = mo.contiguous()
+        gt = gt.to(self.device, non_blocking=True)
+        if gt.dtype != torch.int64 or not gt.is_contiguous():
+            gt = gt.long().contiguous()
+        rc = lib.ovmr_eval_counts(runtime._ptr(mo), runtime.F32 if mo.dtype == torch.float32 else runtime.F16, mo.stride(0),
+                                  runtime._ptr(gt), mo.shape[0], C, runtime._ptr(self._counts), runtime._stream())
+        if rc != 0:
+            raise runtime.OvmrError(f"ovmr_eval_counts failed with {rc}")
+
+    def _process_host(self, mo, gt):
+        """The same three histograms for host tensors (mo.max(1)[1]: lowest column on ties)."""
+        C = self.num_classes
+        pred = mo.float().argmax(dim=1)
+        gt = gt.long()
+        bad = (gt < 0) | (gt >= C)
+        ok = ~bad
+        c = self._counts
+        c[3 * C] += int(bad.sum())
+        c[2 * C:3 * C] += torch.bincount(gt[ok], minlength=C).int()
+        c[C:2 * C] += torch.bincount(pred[ok], minlength=C).int()
+        c[:C] += torch.bincount(gt[ok & (pred == gt)], minlength=C).int()
+
+    def counts(self):
+        """(tp, n_pred, n_label) as int64 host tensors [C]; raises if a label outside [0, C) was seen."""
+        c = self._counts.cpu().long()
+        C = self.num_classes
+        if int(c[3 * C]):
+            raise ValueError(f"{int(c[3 * C])} test label(s) outside [0, {C})")
+        return c[:C], c[C:2 * C], c[2 * C:3 * C]
 
     def evaluate(self, output_dir: Optional[str] = None) -> "OrderedDict[str, float]":
-        tp, n_pred, n_label = (t.double().cpu() for t in (self._tp, self._n_pred, self._n_label))
+        tp, n_pred, n_label = (t.double() for t in self.counts())
         total = float(n_label.sum())
         acc = 100.0 * float(tp.sum()) / max(total, 1.0)
         precision = torch.where(n_pred > 0, tp / n_pred.clamp(min=1), torch.zeros_like(tp))

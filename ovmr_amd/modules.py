@@ -385,9 +385,11 @@ class CustomCLIP:
         return torch.cat(local_labels) if local_labels else torch.zeros(0, dtype=torch.long, device=dev)
 
     @torch.no_grad()
-    def forward_prompt(self, eval_set_loader: Iterable):
+    def forward_prompt(self, eval_set_loader: Iterable, wait_files: bool = True):
         """:214-292.  Returns (mm_classifier, visual_classifer, fusion_weight) and writes
-        mm_classifiers.pt / visual_tokens.pt into cfg.OUTPUT_DIR (rank 0 only when distributed)."""
+        mm_classifiers.pt / visual_tokens.pt into cfg.OUTPUT_DIR (rank 0 only when distributed).
+        wait_files=False (what forward() passes when it generates the classifiers inside a test loop): the files are written behind the
+        caller's back (_write_files) and are complete after wait_files(); the default returns with both files on disk, as the reference does."""
         e, pl, dev = self.engine, self.prompt_learner, self.device
         C, S, D, n_ctx = len(self.tokenized_prompts), self.test_num_ins, e.spec.embed_dim, pl.n_ctx
         dist = self._dist
@@ -423,15 +425,82 @@ class CustomCLIP:
                                                       self.zero_shot_classifier, float(self.cfg.EVAL_TAU))   # :261-274
         assert bool(all_initialized), "a class received no exemplar batch"          # :259
         if rank == 0 and self.cfg.OUTPUT_DIR:
-            os.makedirs(self.cfg.OUTPUT_DIR, exist_ok=True)
-            torch.save({"text_classifier": self.zero_shot_classifier.float(),      # :276-285, all fp32
-                        "vision_classifier": self.visual_classifer.float(),
-                        "mm_classifier": self.mm_classifier.float(),
-                        "fusion_weight": self.fusion_weight.float()},
-                       osp.join(self.cfg.OUTPUT_DIR, "mm_classifiers.pt"))
-            torch.save({"visual_tokens": self.visual_tokens},                       # :286-291, fp16
-                       osp.join(self.cfg.OUTPUT_DIR, "visual_tokens.pt"))
+            self._write_files()
+            if wait_files:
+                self.wait_files()
         return self.mm_classifier, self.visual_classifer, self.fusion_weight
+
+    # ------------------------------------------------------------------ the two output files, off the critical path
+    ASYNC_FILE_WRITE = True       # mm_classifiers.pt / visual_tokens.pt (:276-291) are written by a worker thread behind a side stream while the
+                                  # caller goes on (the query loop of a test pass, the next rank's barrier); False: inline, as the reference does.
+                                  # The files are the same bytes either way (tests/test_hip_parity.py::test_async_file_write_is_byte_identical).
+
+    def _write_files(self):
+        """:276-291.  The saved objects are what the reference saves -- CUDA tensors, fp32 classifiers and fp16 visual tokens -- snapshotted on
+        the caller's stream; `torch.save` itself (device-to-host copies on a side stream, pickling, the zip archive) runs in a worker
+        thread.  wait_files() joins it: forward_prompt calls it before it writes again, MM_CLS_OP.test() / the CLI / bench.py's step
+        before they report, and the interpreter joins the (non-daemon) thread at exit."""
+        self.wait_files()
+        out_dir = self.cfg.OUTPUT_DIR
+        mm = {"text_classifier": self.zero_shot_classifier.float(),               # :276-285, all fp32
+              "vision_classifier": self.visual_classifer.float(),
+              "mm_classifier": self.mm_classifier.float(),
+              "fusion_weight": self.fusion_weight.float()}
+
+        def save(vt):
+            # each archive is written under its own name inside a scratch directory (torch.save names the archive's records after the
+            # file: the bytes are those of a direct torch.save(obj, "<OUTPUT_DIR>/mm_classifiers.pt")) and moved into place whole, so a
+            # reader never finds a half-written file under the final name
+            os.makedirs(out_dir, exist_ok=True)
+            scratch = osp.join(out_dir, f".partial.{os.getpid()}")
+            os.makedirs(scratch, exist_ok=True)
+            try:
+                for obj, name in ((mm, "mm_classifiers.pt"), ({"visual_tokens": vt}, "visual_tokens.pt")):   # :276-291 (visual tokens fp16)
+                    torch.save(obj, osp.join(scratch, name))
+                    os.replace(osp.join(scratch, name), osp.join(out_dir, name))
+            finally:
+                import shutil
+                shutil.rmtree(scratch, ignore_errors=True)
+
+        if not self.ASYNC_FILE_WRITE:
+            save(self.visual_tokens)
+            return
+        import threading
+        vt = self.visual_tokens.clone()                      # (a later forward_prompt allocates new buffers, but a caller may write into this one)
+        on_gpu = self.device.type == "cuda"                  # (the multi-process CPU tests drive this class with a host-side stand-in engine)
+        if on_gpu:
+            cur = torch.cuda.current_stream(self.device)
+            ready = torch.cuda.Event()
+            ready.record(cur)
+            if not hasattr(self, "_file_stream"):
+                self._file_stream = torch.cuda.Stream(self.device)
+            side, dev = self._file_stream, self.device
+
+        def work():
+            try:
+                if not on_gpu:
+                    return save(vt)
+                torch.cuda.set_device(dev)
+                with torch.cuda.stream(side):                # torch.save copies each CUDA storage to the host on the CURRENT stream of this thread
+                    side.wait_event(ready)
+                    save(vt)
+            except BaseException as e:                       # noqa: BLE001 -- re-raised by wait_files() on the caller's thread
+                self._file_error = e
+
+        self._file_error = None
+        self._file_thread = threading.Thread(target=work, name="ovmr-classifier-files", daemon=False)
+        self._file_thread.start()
+
+    def wait_files(self):
+        """Returns once the classifier files of the last forward_prompt are complete on disk (no-op when nothing is in flight); raises what
+        the writer raised."""
+        t = getattr(self, "_file_thread", None)
+        if t is not None:
+            t.join()
+            self._file_thread = None
+            err, self._file_error = getattr(self, "_file_error", None), None
+            if err is not None:
+                raise err
 
     def _xval_fusion_weight(self, local, mm_classifier, v_classifier, t_classifier, tau: float):
         """K18-K20: cross-validation argmax counts on the exemplars this rank encoded (`local` = their class labels,
@@ -483,7 +552,7 @@ class CustomCLIP:
             raise NotImplementedError("the training branch of CustomCLIP.forward (autograd) is out of scope; "
                                       "pass eval_set_loader= to generate the classifiers")
         if self.mm_classifier is None:                                              # :341-342 (the features of `image` do not depend on it)
-            self.forward_prompt(eval_set_loader)
+            self.forward_prompt(eval_set_loader, wait_files=False)                  # the files land while this batch and the next ones run
         if self.SPLIT_FORWARD and 2 * self.SPLIT_MIN_HALF <= image.shape[0] <= self._split_cap():
             return self._forward_split(image)
         return self._forward_on(self.engine, image)
@@ -582,7 +651,7 @@ class CustomCLIP:
         if self.mm_classifier is None:
             if eval_set_loader is None:
                 raise NotImplementedError("pass eval_set_loader= to generate the classifiers")
-            self.forward_prompt(eval_set_loader)
+            self.forward_prompt(eval_set_loader, wait_files=False)
         cur = torch.cuda.current_stream(self.device)
 
         def hand_over(p):

@@ -61,6 +61,7 @@ SIGNATURES = {
     "ovmr_xval_counts": (c_i, [c_p, c_p, c_p, c_i, c_p, c_i, c_p, c_p, c_p]),
     "ovmr_fusion_weights": (c_i, [c_p, c_p, c_p, c_i, ctypes.c_float, c_p, c_p]),
     "ovmr_fused_logits": (c_i, [c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_i, c_i, c_p, c_p]),
+    "ovmr_eval_counts": (c_i, [c_p, c_i, ctypes.c_long, c_p, c_i, c_i, c_p, c_p]),
     "ovmr_zeroshot_logits": (c_i, [c_p, c_p, c_i, c_p, c_i, c_p, c_p]),
     "ovmr_logit_scale": (ctypes.c_float, [c_p]),
     "ovmr_preprocess_u8": (c_i, [c_p, c_i, c_i, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float), c_p, c_p]),

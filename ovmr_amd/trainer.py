@@ -126,6 +126,7 @@ class MM_CLS_OP:
 
         for output in self.model.forward_batches(inputs(), eval_set_loader=self.eval_set_loader):
             self.evaluator.process(output, labels.popleft())
+        self.model.wait_files()                      # mm_classifiers.pt / visual_tokens.pt were written while the test set ran
         results = self.evaluator.evaluate(self.output_dir or None)
         return list(results.values())[0]
 

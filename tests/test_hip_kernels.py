@@ -368,3 +368,97 @@ def test_race_screen_of_hand_synchronised_kernels():
     tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "race_screen.py")
     r = subprocess.run([sys.executable, tool, "--reps", "60"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "RACE SCREEN CLEAN" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("B,C,dtype", [(256, 1000, torch.float32), (37, 10, torch.float16), (513, 1001, torch.float32), (64, 21841, torch.float32),
+                                       (5, 3, torch.float32), (300, 1000, torch.float16)])
+def test_evaluator_counts_kernel_vs_sklearn(lib, tmp_path, B, C, dtype):
+    """`Classification` (Dassl.pytorch/dassl/evaluation/evaluator.py:50-138) on the library's own row-argmax-and-count kernel
+    (ovmr_eval_counts).  Accuracy, error rate, macro-F1 and BOTH per-class CSVs must equal sklearn's on the host copy of the same outputs --
+    with a class that never occurs in the labels, exact ties (lowest column wins, as `mo.max(1)[1]`), rows of identical values, an odd class
+    count (rows not 16-byte aligned), several batches accumulated without a host round trip, fp32 probabilities and fp16 logits."""
+    from sklearn.metrics import f1_score
+    from ovmr_amd.evaluator import Classification
+    rng = np.random.default_rng(B * 7 + C)
+    absent = C - 1 if C > 3 else None
+    gt = rng.integers(0, C - 1 if absent is not None else C, B)
+    out = rng.normal(size=(B, C)).astype(np.float32)
+    out[np.arange(B), gt] += 2.0 * (rng.random(B) < 0.6)
+    out = torch.from_numpy(out).to(dtype)
+    # exact ties: the row maximum copied to a LOWER and a HIGHER column; a constant row; a row of -inf
+    top = out.argmax(1)
+    for r in range(0, B, 5):
+        c = int(top[r])
+        if c > 0:
+            out[r, int(rng.integers(0, c))] = out[r, c]
+        if c + 1 < C:
+            out[r, int(rng.integers(c + 1, C))] = out[r, c]
+    out[1 % B] = 0.25
+    out[2 % B] = float("-inf")
+    want_pred = out.float().numpy().argmax(1)                                   # numpy: first occurrence of the maximum
+    ev = Classification(C, device="cuda")
+    dev_out, dev_gt = out.cuda(), torch.from_numpy(gt).cuda()
+    cuts = [0, B // 3, B // 3, 2 * B // 3 + 1, B]                               # an empty batch among them
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        ev.process(dev_out[a:b], dev_gt[a:b])
+    tp, n_pred, n_label = (t.numpy() for t in ev.counts())
+    assert np.array_equal(n_pred, np.bincount(want_pred, minlength=C)) and np.array_equal(n_label, np.bincount(gt, minlength=C))
+    assert np.array_equal(tp, np.bincount(gt[want_pred == gt], minlength=C))
+    res = ev.evaluate(str(tmp_path))
+    assert res["accuracy"] == pytest.approx(100.0 * float((want_pred == gt).mean()))
+    assert res["error_rate"] == pytest.approx(100.0 - res["accuracy"])
+    present = np.unique(gt)
+    assert res["macro_f1"] == pytest.approx(100.0 * f1_score(gt, want_pred, average="macro", labels=present, zero_division=0))
+    if absent is not None:
+        assert n_label[absent] == 0 and absent not in present
+    f1_rows = open(tmp_path / "f1_per_class.csv").read().strip().split("\n")
+    assert f1_rows[0] == "Label,F1" and len(f1_rows) == 1 + len(present)
+    per_f1 = 100.0 * f1_score(gt, want_pred, average=None, labels=present, zero_division=0)
+    assert [float(x.split(",")[1]) for x in f1_rows[1:]] == pytest.approx(list(per_f1))
+    acc_rows = open(tmp_path / "acc_per_class.csv").read().strip().split("\n")
+    per_acc = {str(c): 100.0 * float((want_pred[gt == c] == c).mean()) for c in present}
+    assert acc_rows[0] == "Label,Acc" and [x.split(",")[0] for x in acc_rows[1:]] == sorted(per_acc)
+    assert {x.split(",")[0]: float(x.split(",")[1]) for x in acc_rows[1:]} == pytest.approx(per_acc)
+    # the host-side evaluator (device="cpu") holds the same counters
+    host = Classification(C, device="cpu")
+    host.process(out, torch.from_numpy(gt))
+    assert all(np.array_equal(a.numpy(), b) for a, b in zip(host.counts(), (tp, n_pred, n_label)))
+
+
+def test_evaluator_counts_kernel_edge_cases(lib):
+    """ovmr_eval_counts at the ABI: a strided view of a wider matrix (ld > C, unaligned rows), NaN (the largest value, first one wins -- torch's
+    rule), int32 labels handed to the Python class, labels outside [0, C) counted apart and raised by the host, argument errors."""
+    from ovmr_amd.evaluator import Classification
+    C, B = 77, 130
+    g = torch.Generator().manual_seed(3)
+    wide = torch.randn((B, C + 9), generator=g)
+    wide[3, 10] = float("nan")
+    wide[3, 40] = float("nan")
+    wide[4, 5 + 3] = float("nan")
+    view = wide[:, 5:5 + C]                                                     # row stride C + 9, first element 20 bytes into the row
+    want = view.argmax(1)                                                       # torch CPU: NaN is the maximum, first occurrence
+    assert int(want[3]) == 5 and int(want[4]) == 3
+    gt = torch.randint(0, C, (B,), generator=g)
+    ev = Classification(C, device="cuda")
+    ev.process(wide.cuda()[:, 5:5 + C], gt.int().cuda())
+    tp, n_pred, n_label = ev.counts()
+    assert torch.equal(n_pred, torch.bincount(want, minlength=C)) and torch.equal(n_label, torch.bincount(gt, minlength=C))
+    assert torch.equal(tp, torch.bincount(gt[want == gt], minlength=C))
+    bad = gt.clone()
+    bad[7], bad[9] = C, -1
+    ev.reset()
+    ev.process(view.cuda(), bad.cuda())
+    with pytest.raises(ValueError, match="2 test label"):
+        ev.counts()
+    with pytest.raises(ValueError):
+        ev.process(torch.zeros(4, C + 1).cuda(), gt[:4].cuda())
+    counts = torch.zeros(3 * C + 1, dtype=torch.int32, device="cuda")
+    x = torch.zeros(4, C, device="cuda")
+    lab = torch.zeros(4, dtype=torch.int64, device="cuda")
+    assert lib.ovmr_eval_counts(_p(x), 1, C - 1, _p(lab), 4, C, _p(counts), _s()) == -1      # ld < C
+    assert lib.ovmr_eval_counts(_p(x), 2, C, _p(lab), 4, C, _p(counts), _s()) == -1          # dtype
+    assert lib.ovmr_eval_counts(None, 1, C, _p(lab), 4, C, _p(counts), _s()) == -1
+    assert lib.ovmr_eval_counts(_p(x), 1, C, _p(lab), 0, C, _p(counts), _s()) == 0
+    assert lib.ovmr_eval_counts(_p(x), 1, C, _p(lab), 4, C, _p(counts), _s()) == 0
+    torch.cuda.synchronize()
+    assert int(counts[C]) == 4 and int(counts[0]) == 4 and int(counts[2 * C]) == 4 and int(counts.sum()) == 12   # all-zero rows: column 0

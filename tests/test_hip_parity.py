@@ -294,6 +294,7 @@ def test_generate_classifier_vs_golden(golden, tmp_path, O, name, key, tag, n_ct
         outs[mode] = model(q, eval_set_loader=loader)
         assert outs[mode].dtype == torch.float32 and outs[mode].shape == (len(qlab), 6)
 
+    model.wait_files()                                                        # (forward() had them written behind its back)
     saved = torch.load(os.path.join(str(tmp_path), "mm_classifiers.pt"), map_location="cpu")
     assert sorted(saved) == ["fusion_weight", "mm_classifier", "text_classifier", "vision_classifier"]
     assert all(v.dtype == torch.float32 for v in saved.values())
@@ -329,6 +330,66 @@ def test_generate_classifier_vs_golden(golden, tmp_path, O, name, key, tag, n_ct
         assert_cosine(outs["fusion"].cpu().numpy()[:, ok], g[f"{tag}_logits_fusion"][:, ok], tol, "fusion (unaffected classes)")
 
 
+def test_async_file_write_is_byte_identical(golden, tmp_path):
+    """mm_classifiers.pt / visual_tokens.pt (trainers/mm_classifier_one_prompt.py:276-291) written by the worker thread behind a side stream
+    (the default: off the critical path of the test loop / of rank 0) are THE SAME BYTES as the inline `torch.save` calls, reload onto the
+    device they were saved from as the reference's do, and a reader never finds a partial file under the final name: forward() returns
+    before the files are complete, wait_files() joins the writer, an explicit forward_prompt() returns with both on disk, a failing write
+    is raised on the caller's thread by wait_files()."""
+    import hashlib
+    from ovmr_amd import modules
+    g = golden("tiny")
+    spec = synth.SPECS["tiny"]
+    S, cpb = int(g["meta_shots"]), int(g["meta_classes_per_batch"])
+    cm = _clip("tiny", 2)
+    pl_sd = {k: torch.from_numpy(v) for k, v in synth.prompt_learner_state_dict(spec, 2, SEED, True).items()}
+    labels = g["l2_eval_labels"]
+    img = synth.images(len(labels), spec.image_resolution, seed=1234, class_ids=labels, class_strength=0.6)
+    loader = [{"img": torch.from_numpy(img[s:s + cpb * S]), "label": torch.from_numpy(labels[s:s + cpb * S])} for s in range(0, len(labels), cpb * S)]
+    q = torch.from_numpy(synth.images(4, spec.image_resolution, seed=777))
+    names = ("mm_classifiers.pt", "visual_tokens.pt")
+
+    def digest(d):
+        return [hashlib.sha256(open(os.path.join(d, n), "rb").read()).hexdigest() for n in names]
+
+    def make(sub, asynchronous):
+        d = str(tmp_path / sub)
+        cfg = modules.make_cfg(n_ctx=2, num_shots=S, eval_tau=float(g["meta_tau"]), output_dir=d)
+        m = modules.CustomCLIP(cfg, torch.from_numpy(g["l2_tokenized_prompts"]), cm, prompt_learner_state=pl_sd, reserve=(64, 64, 256))
+        m.ASYNC_FILE_WRITE = asynchronous
+        return m, d
+
+    m0, d0 = make("inline", False)
+    m0.forward_prompt(loader)
+    want = digest(d0)
+    m1, d1 = make("explicit", True)
+    m1.forward_prompt(loader)                               # default wait_files=True: both files are there on return
+    assert sorted(os.listdir(d1)) == sorted(names) and digest(d1) == want
+    m2, d2 = make("lazy", True)
+    out = m2(q, eval_set_loader=loader)                     # the reference's call: the first forward generates the classifiers (:341-342)
+    for _ in range(3):
+        out = m2(q)
+    m2.wait_files()
+    m2.wait_files()                                         # idempotent
+    assert sorted(os.listdir(d2)) == sorted(names) and digest(d2) == want
+    assert bool(torch.isfinite(out).all())
+    saved = torch.load(os.path.join(d2, "mm_classifiers.pt"))                # no map_location: tensors come back on the device they were saved from
+    assert all(v.is_cuda and v.dtype == torch.float32 for v in saved.values())
+    assert torch.load(os.path.join(d2, "visual_tokens.pt"))["visual_tokens"].is_cuda
+    # a second job into the same directory replaces the files atomically and leaves no temporaries behind
+    m2.forward_prompt(loader, wait_files=False)
+    m2.wait_files()
+    assert sorted(os.listdir(d2)) == sorted(names) and digest(d2) == want
+    # a failing writer surfaces on the caller's thread
+    blocked = tmp_path / "not_a_directory"
+    blocked.write_text("x")
+    m2.cfg.OUTPUT_DIR = str(blocked / "sub")
+    m2.forward_prompt(loader, wait_files=False)
+    with pytest.raises(OSError):
+        m2.wait_files()
+    m2.wait_files()                                         # the error is reported once
+
+
 def _aligned_clip(name, sd_np, pl_np, tag="l2a"):
     from ovmr_amd import modules
     key = (name, "aligned", tag)                      # every aligned case has its own gain, i.e. its own weights
@@ -360,6 +421,7 @@ def test_generate_classifier_vs_golden_aligned(golden, tmp_path, O, key, name, t
     for mode in ("fusion", "text", "vision", "multimodal"):
         cfg.EVAL_MODE = mode
         outs[mode] = model(qt, eval_set_loader=loader).cpu().numpy()
+    model.wait_files()                                                        # (forward() had them written behind its back)
     saved = torch.load(os.path.join(str(tmp_path), "mm_classifiers.pt"), map_location="cpu")
     for k in ("text_classifier", "vision_classifier", "mm_classifier"):
         assert_cosine(saved[k].numpy(), g[f"{tag}_saved_{k}"], COS_TOL, k)
@@ -652,6 +714,36 @@ def test_cli_generate_and_evaluate_end_to_end(tmp_path, O):
         r = O.forward_prompt(img, lab, tok, _oracle_sd(O, "small"), pl_sd, 2, 10.0, 2, "fp16")
     for k in ("text_classifier", "vision_classifier", "mm_classifier"):
         assert_cosine(saved[k].numpy(), r[k].numpy(), COS_TOL, k)
+    # the evaluator's figures (8f-4: Classification on ovmr_eval_counts) against the ORACLE's predictions on the same test images through
+    # sklearn -- accuracy, macro-F1 and both per-class CSVs (Dassl.pytorch/dassl/evaluation/evaluator.py:69-138).  A test row whose
+    # oracle top-2 margin is within fp16 noise may legitimately flip; every such row widens the accuracy bound by one image, and with
+    # none (the case this fixture is built for) everything must be equal
+    from sklearn.metrics import f1_score
+    _, test_items = cli.list_split(str(root), "val")
+    timg = torch.stack([cli.test_transform(Image.open(p), spec.image_resolution) for p, _ in test_items])
+    tlab = np.array([l for _, l in test_items])
+    sd16 = _oracle_sd(O, "small")
+    with torch.no_grad():
+        qf = O.l2_normalize(O.encode_image(timg.half(), sd16))
+        probs = O.inference_logits(qf, r["mm_classifier"].half(), r["vision_classifier"].half(), r["text_classifier"].half(),
+                                   saved["fusion_weight"], sd16["logit_scale"].float().exp(), "fusion").float()
+    # (the job's own fusion weights: this fixture's random-weight cross-validation has near-tied argmaxes, which the generation tests deal
+    #  with; here the question is the test pass -- inference + evaluator -- given the generated classifiers)
+    top2 = probs.topk(2, dim=1).values
+    unclear = int(((top2[:, 0] - top2[:, 1]) < 2e-3).sum())
+    pred = probs.argmax(1).numpy()
+    want_acc = 100.0 * float((pred == tlab).mean())
+    assert abs(res["accuracy"] - want_acc) <= 100.0 * unclear / len(tlab) + 1e-9, (res["accuracy"], want_acc, unclear)
+    assert res["error_rate"] == pytest.approx(100.0 - res["accuracy"])
+    if unclear == 0:
+        assert res["accuracy"] == pytest.approx(want_acc)
+        assert res["macro_f1"] == pytest.approx(100.0 * f1_score(tlab, pred, average="macro", labels=np.unique(tlab)))
+        f1_rows = open(out / "f1_per_class.csv").read().strip().split("\n")
+        per_f1 = 100.0 * f1_score(tlab, pred, average=None, labels=np.unique(tlab))
+        assert f1_rows[0] == "Label,F1" and [float(x.split(",")[1]) for x in f1_rows[1:]] == pytest.approx(list(per_f1))
+        acc_rows = open(out / "acc_per_class.csv").read().strip().split("\n")
+        per_acc = {str(c): 100.0 * float((pred[tlab == c] == c).mean()) for c in np.unique(tlab)}
+        assert acc_rows[0] == "Label,Acc" and {x.split(",")[0]: float(x.split(",")[1]) for x in acc_rows[1:]} == pytest.approx(per_acc)
     assert cli.main(common + ["--output-dir", str(out)]) == {}          # "results exist ... skip this job"
     # the same command line under torch.distributed.run (what scripts/generate_classifier.sh does for several GPUs): two ranks, here over
     # gloo on the test box's one GPU -- the runner opens the process group itself, the classes are sharded over the ranks, rank 0 evaluates
@@ -932,6 +1024,7 @@ def test_config_c5_vit_l14_336_generation_end_to_end(O, tmp_path):
         qf = O.l2_normalize(O.encode_image(q.half(), sd))
     assert_cosine(model.eval_feat4cls.float().cpu().flatten(0, 1).numpy(), r["eval_feat4cls"].float().flatten(0, 1).numpy(), COS_TOL, "eval_feat4cls")
     assert_cosine(model.visual_tokens.float().cpu().flatten(0, 1).numpy(), r["visual_tokens"].float().flatten(0, 1).numpy(), COS_TOL, "visual tokens")
+    model.wait_files()                                                        # (forward() had them written behind its back)
     saved = torch.load(os.path.join(str(tmp_path), "mm_classifiers.pt"), map_location="cpu")
     for k in ("mm_classifier", "vision_classifier", "text_classifier"):
         assert_cosine(saved[k].numpy(), r[k].numpy(), COS_TOL, k)
