@@ -187,6 +187,20 @@ int ovmr_fused_logits(ovmr_handle* h, const void* feats_f16, int B, const void* 
 int ovmr_zeroshot_logits(ovmr_handle* h, const void* feats_f16, int B, const void* text_f16, int C,
                          void* out_f16, ovmr_stream stream);
 
+/* Class-sharded generation (no counterpart in the reference, which has no distributed path: trainers/mm_classifier_one_prompt.py:414-419
+ * wraps the model in nn.DataParallel): a rank's contribution to the job's ONE all-gather.  block [bound, K + 2] fp16 with
+ * K = 3 D + n_ctx D: row i < n = mm[c] | v[c] | t[c] | tokens[c] for c = labels[i] (int64 class ids; mm / v / t are the class-indexed
+ * [C, D] fp16 buffers of forward_prompt, :216-225, tokens [C, n_ctx, D] fp16) followed by c as an int32 bit pattern in two fp16 columns;
+ * rows n <= i < bound are zero with label -1.  D even.  Needs no handle. */
+int ovmr_pack_rows(const void* mm_f16, const void* v_f16, const void* t_f16, const void* tokens_f16, const int64_t* labels, int n,
+                   int D, int n_ctx, int bound, void* block_f16, ovmr_stream stream);
+
+/* The inverse, on the gathered blocks of all ranks ([rows, K + 2] fp16, rank-major): every row whose label lies in [0, C) is written to
+ * row `label` of mm / v / t [C, D] and tokens [C, n_ctx, D]; seen (int32 [C + 1], zeroed by the caller) counts the rows per class -- the
+ * job is complete iff seen[c] == 1 for every class (:259) -- and, in seen[C], labels outside [-1, C). */
+int ovmr_unpack_rows(const void* gathered_f16, int rows, int C, int D, int n_ctx, void* mm_f16, void* v_f16, void* t_f16,
+                     void* tokens_f16, int32_t* seen, ovmr_stream stream);
+
 /* Classification.process of the test loop (Dassl.pytorch/dassl/evaluation/evaluator.py:50-67): outputs [B, C] (fp32 = what
  * CustomCLIP.forward returns, or fp16 = ZeroshotCLIP's raw logits; row stride ld elements), labels int64 [B] (the batch's LongTensor as
  * it is).  pred = outputs.max(1)[1] -- lowest column on ties, a NaN is the largest value -- then counts[0][pred] += (pred == label)

@@ -177,6 +177,10 @@ int launch_text_embed_ids(const int64_t* ids, int ids_stride, const float* tok_e
 int launch_embed_gather(const int64_t* ids, const float* tok_emb, half_t* out, long rows, int D, hipStream_t s);
 int launch_text_add_pos(const half_t* prompts, int Lctx, const half_t* pos16, half_t* x, int N, int Lseq, int D, hipStream_t s);
 int launch_gather_rows_f16(const half_t* x, const int* index, half_t* out, int N, int Lseq, int D, hipStream_t s);
+int launch_pack_rows(const half_t* mm, const half_t* v, const half_t* t, const half_t* tokens, const int64_t* labels, int n, int D, int n_ctx,
+                     int bound, half_t* block, hipStream_t s);
+int launch_unpack_rows(const half_t* gathered, int rows, int C, int D, int n_ctx, half_t* mm, half_t* v, half_t* t, half_t* tokens, int* seen,
+                       hipStream_t s);
 int launch_agg_input(const float* cls_token, const half_t* feats, float* x, int Cb, int S, int n_ctx, int D, hipStream_t s);
 int launch_agg_output(const float* x, float* tokens, int Cb, int La, int n_ctx, int D, hipStream_t s);
 int launch_assemble_prompts(const half_t* base, const int64_t* labels, const float* tokens, half_t* out,

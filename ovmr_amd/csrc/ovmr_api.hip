@@ -833,6 +833,22 @@ int ovmr_fusion_weights(ovmr_handle* h, const int32_t* counts, const int32_t* n_
     return 0;
 }
 
+int ovmr_pack_rows(const void* mm, const void* v, const void* t, const void* tokens, const int64_t* labels, int n, int D, int n_ctx, int bound,
+                   void* block, ovmr_stream stream) {
+    if (bound == 0) return 0;
+    if (!mm || !v || !t || !tokens || !block || (n > 0 && !labels) || n < 0 || bound < n || D < 2 || (D & 1) || n_ctx < 1) return OVMR_E_ARG;
+    return launch_pack_rows((const half_t*)mm, (const half_t*)v, (const half_t*)t, (const half_t*)tokens, labels, n, D, n_ctx, bound,
+                            (half_t*)block, (hipStream_t)stream);
+}
+
+int ovmr_unpack_rows(const void* gathered, int rows, int C, int D, int n_ctx, void* mm, void* v, void* t, void* tokens, int32_t* seen,
+                     ovmr_stream stream) {
+    if (rows == 0) return 0;
+    if (!gathered || !mm || !v || !t || !tokens || !seen || rows < 0 || C < 1 || D < 2 || (D & 1) || n_ctx < 1) return OVMR_E_ARG;
+    return launch_unpack_rows((const half_t*)gathered, rows, C, D, n_ctx, (half_t*)mm, (half_t*)v, (half_t*)t, (half_t*)tokens, seen,
+                              (hipStream_t)stream);
+}
+
 int ovmr_eval_counts(const void* outputs, int dtype, long ld, const int64_t* labels, int B, int C, int32_t* counts, ovmr_stream stream) {
     if (B == 0) return 0;
     if (!outputs || !labels || !counts || B < 0 || C < 1 || ld < C || (dtype != OVMR_F16 && dtype != OVMR_F32)) return OVMR_E_ARG;

@@ -179,6 +179,49 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const half_t* __restri
     for (int c = lane * 4; c < D; c += 256) *(half4_t*)(out + (long)n * D + c) = *(const half4_t*)(s + c);
 }
 
+// The sharded job's ONE packed all-gather (ovmr_amd/shard.py pack_block): a rank's block is [bound, K + 2] fp16 with
+// K = 3 D + n_ctx D -- row i = mm | vision | text classifier rows and the visual tokens of class labels[i], the class's int32 label as two
+// fp16 bit columns; rows i >= n are zero with label -1.  Rows are 4-byte aligned (K + 2 is even), not 16: 4-byte moves.
+__global__ __launch_bounds__(256) void pack_rows_kernel(const half_t* __restrict__ mm, const half_t* __restrict__ v, const half_t* __restrict__ t,
+                                                        const half_t* __restrict__ tokens, const int64_t* __restrict__ labels, int n, int D,
+                                                        int n_ctx, half_t* __restrict__ block) {
+    const int i = blockIdx.x, K = (3 + n_ctx) * D;
+    unsigned* dst = (unsigned*)(block + (long)i * (K + 2));
+    const long c = i < n ? labels[i] : -1;
+    const int D2 = D / 2, K2 = K / 2;
+    for (int k = threadIdx.x; k < K2; k += 256) {
+        unsigned val = 0;
+        if (i < n) {
+            const int part = k / D2, o = k - part * D2;
+            const half_t* src = part == 0 ? mm + c * D : part == 1 ? v + c * D : part == 2 ? t + c * D : tokens + c * (long)n_ctx * D + (long)(part - 3) * D;
+            val = ((const unsigned*)src)[o];
+        }
+        dst[k] = val;
+    }
+    if (threadIdx.x == 0) dst[K2] = (unsigned)(int)c;
+}
+
+// ... and its inverse on the gathered [rows, K + 2] blocks of all ranks: every row with a label in [0, C) lands in the four class-indexed
+// arrays, seen[label] counts it (a class must arrive exactly once); labels outside [-1, C) are counted in seen[C].
+__global__ __launch_bounds__(256) void unpack_rows_kernel(const half_t* __restrict__ gathered, int C, int D, int n_ctx, half_t* __restrict__ mm,
+                                                          half_t* __restrict__ v, half_t* __restrict__ t, half_t* __restrict__ tokens,
+                                                          int* __restrict__ seen) {
+    const int K = (3 + n_ctx) * D, D2 = D / 2, K2 = K / 2;
+    const unsigned* src = (const unsigned*)(gathered + (long)blockIdx.x * (K + 2));
+    const int c = (int)src[K2];
+    if (c < 0 || c >= C) {
+        if (threadIdx.x == 0 && c != -1) atomicAdd(seen + C, 1);
+        return;
+    }
+    if (threadIdx.x == 0) atomicAdd(seen + c, 1);
+    for (int k = threadIdx.x; k < K2; k += 256) {
+        const int part = k / D2, o = k - part * D2;
+        half_t* dst = part == 0 ? mm + (long)c * D : part == 1 ? v + (long)c * D : part == 2 ? t + (long)c * D
+                                                                                 : tokens + (long)c * n_ctx * D + (long)(part - 3) * D;
+        ((unsigned*)dst)[o] = src[k];
+    }
+}
+
 // PromptLearner.forward (trainers/mm_classifier_one_prompt.py:167-168): cat([cls_token, feats]) in fp32
 __global__ __launch_bounds__(256) void agg_input_kernel(const float* __restrict__ cls, const half_t* __restrict__ feats,
                                                         float* __restrict__ x, int Cb, int S, int n_ctx, int D) {
@@ -344,6 +387,18 @@ int launch_text_add_pos(const half_t* prompts, int Lctx, const half_t* pos16, ha
 int launch_gather_rows_f16(const half_t* x, const int* index, half_t* out, int N, int Lseq, int D, hipStream_t s) {
     if (N <= 0) return 0;
     hipLaunchKernelGGL(gather_rows_kernel, dim3((N + 3) / 4), dim3(256), 0, s, x, index, out, N, Lseq, D);
+    return (int)hipGetLastError();
+}
+int launch_pack_rows(const half_t* mm, const half_t* v, const half_t* t, const half_t* tokens, const int64_t* labels, int n, int D, int n_ctx,
+                     int bound, half_t* block, hipStream_t s) {
+    if (bound <= 0) return 0;
+    hipLaunchKernelGGL(pack_rows_kernel, dim3(bound), dim3(256), 0, s, mm, v, t, tokens, labels, n, D, n_ctx, block);
+    return (int)hipGetLastError();
+}
+int launch_unpack_rows(const half_t* gathered, int rows, int C, int D, int n_ctx, half_t* mm, half_t* v, half_t* t, half_t* tokens, int* seen,
+                       hipStream_t s) {
+    if (rows <= 0) return 0;
+    hipLaunchKernelGGL(unpack_rows_kernel, dim3(rows), dim3(256), 0, s, gathered, C, D, n_ctx, mm, v, t, tokens, seen);
     return (int)hipGetLastError();
 }
 int launch_agg_input(const float* cls_token, const half_t* feats, float* x, int Cb, int S, int n_ctx, int D, hipStream_t s) {

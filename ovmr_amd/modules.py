@@ -379,7 +379,8 @@ class CustomCLIP:
                 mm, v = self.get_mm_v_feats(mm_p, mm_l, v_p, v_l)                   # :249
             self.mm_classifier[exemplar_label] = mm                                 # :251
             self.visual_classifer[exemplar_label] = v                               # :252
-            self.inference_text_initialized[exemplar_label] = 1                     # :254
+            self.inference_text_initialized.index_fill_(0, exemplar_label, 1)       # :254 (`[...] = 1` copies the scalar from the host:
+                                                                                    #  a synchronisation in the middle of the head)
             self.visual_tokens[exemplar_label] = tokens.half()                      # :255
             local_labels.append(exemplar_label)
         return torch.cat(local_labels) if local_labels else torch.zeros(0, dtype=torch.long, device=dev)
@@ -402,25 +403,20 @@ class CustomCLIP:
         streamed_text, text_clf = self._text_streamed, self._text_rows
 
         if dist:
-            # ONE all-gather (RCCL) of the packed classifier rows: [mm | v | text | tokens | label bits]
-            from .shard import all_gather_rows, local_class_bound
-            packed = torch.cat([self.mm_classifier[local], self.visual_classifer[local], text_clf[local],
-                                self.visual_tokens[local].flatten(1)], dim=1)
+            # ONE all-gather (RCCL) of the packed classifier rows: [mm | v | text | tokens | label bits]; packing and
+            # unpacking are one launch each (ovmr_pack_rows / ovmr_unpack_rows) -- a dozen indexing kernels before
+            from .shard import all_gather_block, local_class_bound
             bound = local_class_bound(C, world, presharded, cpb)
-            rows, labels = all_gather_rows(packed, local, bound, dist)
-            full = torch.zeros((C + 1, rows.shape[1]), **f16)                       # row C collects the padding rows
-            full.index_copy_(0, torch.where(labels >= 0, labels, C).long(), rows)
-            seen = torch.zeros(C + 1, dtype=torch.int32, device=dev)
-            seen.index_add_(0, torch.where(labels >= 0, labels, C).long(), torch.ones_like(labels))
-            self.mm_classifier = full[:C, :D].contiguous()
-            self.visual_classifer = full[:C, D:2 * D].contiguous()
-            text_clf = full[:C, 2 * D:3 * D].contiguous()
-            self.visual_tokens = full[:C, 3 * D:].reshape(C, n_ctx, D).contiguous()
+            block = e.pack_rows(self.mm_classifier, self.visual_classifer, text_clf, self.visual_tokens, local, bound)
+            gathered = all_gather_block(block, dist)
+            self.mm_classifier, self.visual_classifer, text_clf, self.visual_tokens, seen = e.unpack_rows(gathered, C, D, n_ctx)
             self.inference_text_initialized = (seen[:C] == 1).to(torch.int32)       # every class from exactly one rank
+            self._stray_rows = seen[C:]
         if streamed_text:
             self.zero_shot_classifier = self.prompt_learner.zero_shot_classifier = text_clf
         all_initialized = self.inference_text_initialized.bool().all()              # :259 -- read back below, behind the enqueued head:
-                                                                                    # a host round trip here would idle the GPU in front of it
+        if dist:                                                                    # a host round trip here would idle the GPU in front of it
+            all_initialized = all_initialized & (self._stray_rows == 0).all()
         self.fusion_weight = self._xval_fusion_weight(local, self.mm_classifier, self.visual_classifer,
                                                       self.zero_shot_classifier, float(self.cfg.EVAL_TAU))   # :261-274
         assert bool(all_initialized), "a class received no exemplar batch"          # :259
@@ -510,13 +506,15 @@ class CustomCLIP:
         counts = torch.zeros((3, 2, C), dtype=torch.int32, device=dev)
         if local.numel():
             rows = self.eval_feat4cls[local].flatten(0, 1)
-            row_labels = local.to(torch.int32).repeat_interleave(S)                # :261
+            row_labels = local.to(torch.int32).unsqueeze(1).expand(-1, S).reshape(-1)   # :261 (repeat_interleave: five launches for the same rows)
             for m, clf in enumerate((mm_classifier, v_classifier, t_classifier)):   # order :272
                 e.xval_counts(rows, row_labels, clf, counts[m, 0], counts[m, 1])
         if dist:
             from .shard import all_reduce_counts
             counts = all_reduce_counts(counts, dist)                                # ONE all-reduce
-        n_label = torch.full((C,), S, dtype=torch.int32, device=dev)
+        if getattr(self, "_n_label_key", None) != (C, S):
+            self._n_label, self._n_label_key = torch.full((C,), S, dtype=torch.int32, device=dev), (C, S)
+        n_label = self._n_label
         self.xval_counts = counts
         return e.fusion_weights(counts, n_label, tau)
 

@@ -61,6 +61,8 @@ SIGNATURES = {
     "ovmr_xval_counts": (c_i, [c_p, c_p, c_p, c_i, c_p, c_i, c_p, c_p, c_p]),
     "ovmr_fusion_weights": (c_i, [c_p, c_p, c_p, c_i, ctypes.c_float, c_p, c_p]),
     "ovmr_fused_logits": (c_i, [c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_i, c_i, c_p, c_p]),
+    "ovmr_pack_rows": (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p]),
+    "ovmr_unpack_rows": (c_i, [c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p]),
     "ovmr_eval_counts": (c_i, [c_p, c_i, ctypes.c_long, c_p, c_i, c_i, c_p, c_p]),
     "ovmr_zeroshot_logits": (c_i, [c_p, c_p, c_i, c_p, c_i, c_p, c_p]),
     "ovmr_logit_scale": (ctypes.c_float, [c_p]),
@@ -330,6 +332,32 @@ class Engine:
         self._ck(self.lib.ovmr_fusion_weights(self.h, _ptr(counts), _ptr(n_label), C, float(tau), _ptr(out), _stream()),
                  "ovmr_fusion_weights")
         return out
+
+    def pack_rows(self, mm, v, t, tokens, labels, bound: int) -> torch.Tensor:
+        """One rank's block of the sharded job's all-gather (ovmr_amd/shard.py pack_block, one launch): rows `labels` of the class-indexed
+        fp16 buffers mm / v / t [C, D] and tokens [C, n_ctx, D] + the label bits, [bound, 3 D + n_ctx D + 2] fp16."""
+        n, (C, D), n_ctx = int(labels.shape[0]), mm.shape, tokens.shape[1]
+        if n > bound:
+            raise RuntimeError(f"this rank produced {n} classes, more than the bound {bound} every rank agreed on: the eval-set "
+                               "loader yields more than TEST.BATCH_SIZE // NUM_SHOTS classes per batch")
+        for x in (mm, v, t, tokens):
+            assert x.dtype == torch.float16 and x.is_contiguous() and x.is_cuda
+        labels = self._dev(labels, torch.int64)
+        block = torch.empty((bound, (3 + n_ctx) * D + 2), dtype=torch.float16, device=self.device)
+        self._ck(self.lib.ovmr_pack_rows(_ptr(mm), _ptr(v), _ptr(t), _ptr(tokens), _ptr(labels), n, D, n_ctx, bound, _ptr(block), _stream()),
+                 "ovmr_pack_rows")
+        return block
+
+    def unpack_rows(self, gathered: torch.Tensor, C: int, D: int, n_ctx: int):
+        """The gathered blocks of all ranks -> (mm, v, t [C, D], tokens [C, n_ctx, D], seen int32 [C + 1]); one launch (each result owns its storage: they are saved to files)."""
+        gathered = self._dev(gathered, torch.float16)
+        assert gathered.shape[1] == (3 + n_ctx) * D + 2
+        z = dict(dtype=torch.float16, device=self.device)                                      # (a class no rank sent stays zero; seen says so)
+        mm, v, t, tokens = torch.zeros((C, D), **z), torch.zeros((C, D), **z), torch.zeros((C, D), **z), torch.zeros((C, n_ctx, D), **z)
+        seen = torch.zeros(C + 1, dtype=torch.int32, device=self.device)
+        self._ck(self.lib.ovmr_unpack_rows(_ptr(gathered), gathered.shape[0], C, D, n_ctx, _ptr(mm), _ptr(v), _ptr(t), _ptr(tokens), _ptr(seen),
+                                           _stream()), "ovmr_unpack_rows")
+        return mm, v, t, tokens, seen
 
     def fused_logits(self, feats, mm, v, t, w, mode: str = "fusion", out: Optional[torch.Tensor] = None) -> torch.Tensor:
         feats = self._dev(feats, torch.float16)

@@ -75,6 +75,15 @@ def all_gather_rows(rows: torch.Tensor, labels: torch.Tensor, bound: int, dist) 
     return out[:, :K], out[:, K:].contiguous().view(torch.int32).reshape(-1)
 
 
+def all_gather_block(block: torch.Tensor, dist) -> torch.Tensor:
+    """ONE all-gather of every rank's `pack_block`-format block [bound, K + 2] fp16 (Engine.pack_rows builds it in one launch) ->
+    [world * bound, K + 2], rank-major, on the block's device."""
+    b = _staged(block, dist)
+    out = torch.empty((dist.get_world_size() * b.shape[0], b.shape[1]), dtype=torch.float16, device=b.device)
+    dist.all_gather_into_tensor(out, b)
+    return out.to(block.device)
+
+
 def all_reduce_counts(counts: torch.Tensor, dist) -> torch.Tensor:
     """ONE all-reduce (sum) of the int32 [3, 2, C] argmax counters."""
     c = _staged(counts, dist)

@@ -250,6 +250,29 @@ def images(n: int, resolution: int, seed: int = 1234, class_ids: Optional[np.nda
     return out.reshape(n, 3, resolution, resolution)
 
 
+def trained_like_statistics(sd: Dict[str, np.ndarray], spec: ModelSpec, seed: int = 17) -> np.ndarray:
+    """In place: give a CLIP-init state dict the statistics a TRAINED CLIP ViT shows and init weights do not (every other parity fixture is
+    CLIP-init): a few residual-stream channels with massive activations (tens of standard deviations, appearing after an early MLP and
+    carried to the end), LayerNorm gains that are tiny on those channels and spread over 0.1 .. 4 elsewhere, peaky attention (large q / k),
+    c_fc pre-activations far into both QuickGELU tails.  Returns the hot channels.  Same draws on every platform (numpy PCG64 stream of
+    `seed`): tests/golden/gen_golden.py feeds these weights to the real reference (`hot.npz`), the GPU test regenerates them."""
+    rng = np.random.default_rng(seed)
+    W = spec.vision_width
+    hot = rng.choice(W, size=3, replace=False)
+    sd["visual.transformer.resblocks.0.mlp.c_proj.bias"][hot] = np.array([42.0, -31.0, 18.0], dtype=np.float32)
+    for i in range(spec.vision_layers):
+        q = f"visual.transformer.resblocks.{i}."
+        for ln in ("ln_1", "ln_2"):
+            g = np.exp(rng.normal(0.0, 0.8, W)).clip(0.1, 4.0).astype(np.float32)
+            g[hot] = 0.03
+            sd[q + ln + ".weight"] = g
+            sd[q + ln + ".bias"] = rng.normal(0.0, 0.3, W).astype(np.float32)
+        sd[q + "attn.in_proj_weight"][:2 * W] *= 2.5                 # q and k rows: logits ~6x wider
+        sd[q + "mlp.c_fc.bias"] = rng.normal(0.0, 2.5, 4 * W).astype(np.float32)
+    sd["visual.ln_post.weight"][hot] = 0.05
+    return hot
+
+
 def align_state_dicts(sd: Dict[str, np.ndarray], pl: Dict[str, np.ndarray], spec: ModelSpec, gain: float) -> None:
     """Give random-init weights the ONE property of trained OVMR weights the cross-validation step (K18-K20) relies on:
     classifier rows that point towards their own class's image features.  In place, on fp32 state dicts:

@@ -16,7 +16,7 @@ multiclass_f1_score is the one stub that carries arithmetic; it is restated from
 torcheval 0.0.7's published algorithm (argmax -> tp/n_pred/n_label -> 2pr/(p+r) ->
 nan_to_num), see oracle/ovmr_oracle.py:multiclass_f1_per_class.
 
-Usage:  PYTHONDONTWRITEBYTECODE=1 python tests/golden/gen_golden.py [--only tiny|vitb16|tok]
+Usage:  PYTHONDONTWRITEBYTECODE=1 python tests/golden/gen_golden.py [--only tiny|small|vitb16|tok|hot|c1]
 """
 from __future__ import annotations
 
@@ -326,6 +326,72 @@ def gen_l2_aligned(ref_model, ref_l2, spec, seed, gain, out, tag="l2a", C=12, sh
     return stats
 
 
+# ----------------------------------------------------------------------------- `hot`: trained-like statistics through the real reference
+HOT = dict(spec="ViT-B/16", seed=11, stat_seed=17, n_img=8, img_seed=5, strength=0.7, tile=16)
+
+
+@torch.no_grad()
+def gen_hot(ref_model, out):
+    """The REAL clip/model.py (fp16 after convert_weights, and .float()) on ViT-B/16 -- all 12 blocks -- with
+    synth.trained_like_statistics applied to the CLIP-init weights: massive-activation channels, skewed LayerNorm gains, peaky
+    attention, saturated QuickGELU inputs.  Pins the engine's two default numerics deviations (LayerNorm fold, one-rounding QuickGELU)
+    with the reference itself where CLIP-init statistics cannot (tests/test_hip_parity.py::test_encoder_under_trained_like_statistics)."""
+    spec = synth.SPECS[HOT["spec"]]
+    sd_np = synth.clip_state_dict(spec, HOT["seed"], jitter=True)
+    hot = synth.trained_like_statistics(sd_np, spec, HOT["stat_seed"])
+    img = torch.from_numpy(synth.images(HOT["n_img"], spec.image_resolution, seed=HOT["img_seed"], class_ids=np.arange(HOT["n_img"]) % 4,
+                                        class_strength=HOT["strength"], tile=HOT["tile"]))
+    sd = {k: torch.from_numpy(v) for k, v in sd_np.items()}
+    for tag, fp32 in (("fp16", False), ("fp32", True)):
+        m = ref_model.build_model(dict(sd))
+        m = (m.float() if fp32 else m).eval()
+        f = m.encode_image(img.to(m.dtype))
+        assert bool(torch.isfinite(f).all())
+        out[f"hot_{tag}_image_features"] = f.float().numpy()
+        # the residual stream in front of ln_post, CLS rows: where the massive channels live (magnitude recorded for the test's report)
+        v = m.visual
+        t = v.conv1(img.to(m.dtype))
+        t = t.reshape(t.shape[0], t.shape[1], -1).permute(0, 2, 1)
+        t = torch.cat([v.class_embedding.to(t.dtype) + torch.zeros(t.shape[0], 1, t.shape[-1], dtype=t.dtype), t], 1)
+        t = v.ln_pre(t + v.positional_embedding.to(t.dtype)).permute(1, 0, 2)
+        t = v.transformer(t).permute(1, 0, 2)
+        out[f"hot_{tag}_cls_stream"] = t[:, 0].float().numpy()
+    out["hot_channels"] = hot.astype(np.int64)
+    for k, v in HOT.items():
+        out[f"hot_meta_{k}"] = np.array(v)
+
+
+# ----------------------------------------------------------------------------- `c1`: BASELINE.json configuration 1 (zero-shot CLIP, 10 classes)
+C1_CLASSES = ["accordion", "airplane", "anchor", "ant", "barrel", "bass", "beaver", "binocular", "bonsai", "brain"]   # the first ten Caltech-101
+C1 = dict(spec="ViT-B/16", seed=11, n_img=16, img_seed=1234)                                                          # categories, alphabetically
+
+
+@torch.no_grad()
+def gen_c1(ref_model, ref_clip, out):
+    """trainers/zsclip.py:32-60 on a 10-class Caltech-101 subset, restated line by line on the real `CLIP` module (the trainer file needs
+    dassl to import): prompts = CUSTOM_TEMPLATES["Caltech101"].format(name) tokenised by the REAL clip.tokenize (:42-45), text features
+    normalised (:49-50), per batch normalised image features (:56-57) and logit_scale.exp() * f @ t.T (:58-59) -- in the fp16 model (the
+    GPU path of the reference) and after .float() (what clip.load does on a CPU device, clip/clip.py:130-131)."""
+    spec = synth.SPECS[C1["spec"]]
+    prompts = ["a photo of a {}.".format(c.replace("_", " ")) for c in C1_CLASSES]        # :22, :42-43
+    ids = torch.cat([ref_clip.tokenize(p) for p in prompts])                              # :45
+    img = torch.from_numpy(synth.images(C1["n_img"], spec.image_resolution, seed=C1["img_seed"]))
+    out["c1_prompts"] = np.array(prompts)
+    out["c1_token_ids"] = ids.numpy()
+    for tag, fp32 in (("fp16", False), ("fp32", True)):
+        m = build_ref_clip(ref_model, spec, C1["seed"], True, fp32)
+        tf = m.encode_text(ids)
+        tf = tf / tf.norm(dim=-1, keepdim=True)                                           # :49-50
+        f = m.encode_image(img.to(m.dtype))
+        f = f / f.norm(dim=-1, keepdim=True)                                              # :56-57
+        logits = m.logit_scale.exp() * f @ tf.t()                                         # :58-59
+        out[f"c1_{tag}_text_features"] = tf.float().numpy()
+        out[f"c1_{tag}_image_features"] = f.float().numpy()
+        out[f"c1_{tag}_logits"] = logits.float().numpy()
+    for k, v in C1.items():
+        out[f"c1_meta_{k}"] = np.array(v)
+
+
 def gen_tokenizer(ref_clip, out):
     names = ["a .", "a accordion.", "a bass guitar.", "a sea horse.", "a photo of a yin yang.",
              "a great white shark.", "a toilet tissue.", "a hen-of-the-woods.", "a jack-o'-lantern.", "a T-shirt.",
@@ -350,6 +416,14 @@ def main():
         gen_tokenizer(ref_clip, out)
         np.savez_compressed(os.path.join(HERE, "tokenizer.npz"), **out)
         print("tokenizer.npz", {k: v.shape for k, v in out.items()})
+
+    for key, fn in (("hot", lambda o: gen_hot(ref_model, o)), ("c1", lambda o: gen_c1(ref_model, ref_clip, o))):
+        if args.only in ("all", key):
+            out = {}
+            fn(out)
+            path = os.path.join(HERE, {"hot": "hot.npz", "c1": "c1_zeroshot.npz"}[key])
+            np.savez_compressed(path, **out)
+            print(path, os.path.getsize(path) // 1024, "KiB", {k: v.shape for k, v in out.items() if v.ndim})
 
     for name, n_img, taps, shots, cpb, nq in (("tiny", 4, True, 4, 2, 5), ("small", 3, True, 4, 4, 5),
                                                ("ViT-B/16", 8, False, 4, 2, 5)):

@@ -74,6 +74,22 @@ class OracleEngine:
         return [self.encode_text_ids(g["ids"], g.get("seq_len"), g.get("normalize", 0)) if g.get("ids") is not None else
                 self.encode_text_embedded(g["prompts"], g["index"], g.get("seq_len"), g.get("normalize", 0)) for g in groups]
 
+    def pack_rows(self, mm, v, t, tokens, labels, bound):
+        from ovmr_amd.shard import pack_block
+        labels = labels.long()
+        return pack_block(torch.cat([mm[labels], v[labels], t[labels], tokens[labels].flatten(1)], dim=1), labels, bound)
+
+    def unpack_rows(self, gathered, C, D, n_ctx):
+        K = (3 + n_ctx) * D
+        labels = gathered[:, K:].contiguous().view(torch.int32).reshape(-1).long()
+        ok = (labels >= 0) & (labels < C)
+        full = torch.zeros((C, K), dtype=torch.float16)
+        full[labels[ok]] = gathered[ok, :K]
+        seen = torch.zeros(C + 1, dtype=torch.int32)
+        seen.index_add_(0, torch.where(ok, labels, torch.full_like(labels, C)), ((labels != -1) | ok).int())
+        return (full[:, :D].contiguous(), full[:, D:2 * D].contiguous(), full[:, 2 * D:3 * D].contiguous(),
+                full[:, 3 * D:].reshape(C, n_ctx, D).contiguous(), seen)
+
     def xval_counts(self, feats, labels, clf, tp, n_pred):
         lg = (self.logit_scale * (feats @ clf.t())).float()
         pred = lg.argmax(1)

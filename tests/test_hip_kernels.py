@@ -462,3 +462,42 @@ def test_evaluator_counts_kernel_edge_cases(lib):
     assert lib.ovmr_eval_counts(_p(x), 1, C, _p(lab), 4, C, _p(counts), _s()) == 0
     torch.cuda.synchronize()
     assert int(counts[C]) == 4 and int(counts[0]) == 4 and int(counts[2 * C]) == 4 and int(counts.sum()) == 12   # all-zero rows: column 0
+
+
+@pytest.mark.parametrize("C,D,n_ctx,n,bound", [(1000, 512, 2, 125, 125), (37, 64, 1, 5, 9), (64, 768, 2, 0, 8), (10, 128, 3, 10, 10)])
+def test_pack_and_unpack_rows_of_the_sharded_all_gather(lib, C, D, n_ctx, n, bound):
+    """a rank's block of the job's ONE all-gather (ovmr_pack_rows) is bit for bit `ovmr_amd.shard.pack_block` of the
+    concatenated rows -- mm | vision | text | visual tokens | the int32 label as two fp16 bit columns, zero padding rows labelled -1 --
+    and ovmr_unpack_rows scatters the gathered blocks of all ranks back: every class exactly once (`seen`), stray labels counted apart."""
+    from ovmr_amd import synth
+    from ovmr_amd.runtime import Engine
+    from ovmr_amd.shard import pack_block
+    e = Engine(synth.SPECS["tiny"], 2)                                   # (pack / unpack need no weights: only the binding)
+    g = torch.Generator(device="cuda").manual_seed(C + D)
+    mm, v, t = (torch.randn((C, D), generator=g, device="cuda").half() for _ in range(3))
+    tok = torch.randn((C, n_ctx, D), generator=g, device="cuda").half()
+    labels = torch.randperm(C, generator=g, device="cuda")[:n]
+    block = e.pack_rows(mm, v, t, tok, labels, bound)
+    want = pack_block(torch.cat([mm[labels], v[labels], t[labels], tok[labels].flatten(1)], dim=1), labels, bound)
+    assert block.shape == want.shape and torch.equal(block.view(torch.int16), want.view(torch.int16))
+    with pytest.raises(RuntimeError, match="more than the bound"):
+        e.pack_rows(mm, v, t, tok, torch.arange(bound + 1, device="cuda") % C, bound)
+    # three "ranks": this block, a block of the remaining classes, an empty block -- and back
+    rest = torch.tensor(sorted(set(range(C)) - set(labels.tolist())), device="cuda", dtype=torch.int64)
+    blocks = [block, e.pack_rows(mm, v, t, tok, rest, max(1, C - n)), e.pack_rows(mm, v, t, tok, rest[:0], 4)]
+    K = (3 + n_ctx) * D
+    gathered = torch.cat([b.reshape(-1, K + 2) for b in blocks])
+    mm2, v2, t2, tok2, seen = e.unpack_rows(gathered, C, D, n_ctx)
+    assert torch.equal(mm2, mm) and torch.equal(v2, v) and torch.equal(t2, t) and torch.equal(tok2, tok)
+    assert bool((seen[:C] == 1).all()) and int(seen[C]) == 0
+    # a class sent twice, a class never sent, a label outside the vocabulary
+    bad = gathered.clone()
+    lab = bad[:, K:].contiguous().view(torch.int32).reshape(-1)
+    first = int((lab >= 0).nonzero()[0])
+    second = int((lab >= 0).nonzero()[1]) if C > 1 else first
+    dup, lost = int(lab[first]), int(lab[second])
+    lab[second] = dup
+    lab[int((lab >= 0).nonzero()[-1])] = C + 5
+    bad[:, K:] = lab.view(torch.float16).reshape(-1, 2)
+    seen = e.unpack_rows(bad, C, D, n_ctx)[4]
+    assert int(seen[dup]) == 2 and int(seen[lost]) == 0 and int(seen[C]) == 1
