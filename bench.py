@@ -35,11 +35,13 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 
-# One-flag lines for the configurations of BASELINE.json ("metric" = configs[3]-style headline job = the default; c2 / c3 / c5 =
-# configs[1] / [2] / [4] at N = 1).  A preset only overrides defaults; explicit flags win.  For c3 the VALUE is the inference phase
+# One-flag lines for the configurations of BASELINE.json ("metric" = configs[3]-style headline job = the default; c1 / c2 / c3 / c4 / c5 =
+# configs[0] / [1] / [2] / [3] / [4] at N = 1).  A preset only overrides defaults; explicit flags win.  For c3 the VALUE is the inference phase
 # alone (query images / s: generation is set-up there), for the others the whole job as for the metric.
 PRESETS = {
     "metric": {"about": "ViT-B/16, 1000 classes x 16 shots + 4096 queries (the headline metric)", "set": {}},
+    "c1": {"about": "CLIP ViT-B/16 zero-shot (trainers/zsclip.py), 10 classes, the test loop at batch 256; value = test images/s",
+           "set": {"classes": 10, "queries": 16384}, "value": "zeroshot"},
     "c2": {"about": "ViT-B/16, 100 classes x 8 shots generation + 1024 queries", "set": {"classes": 100, "shots": 8, "queries": 1024, "classes_per_batch": 100}},
     "c3": {"about": "ViT-B/16 fusion inference at batch 256 against 1000 x 16-shot classifiers; value = inference images/s",
            "set": {"queries": 16384}, "value": "inference"},
@@ -110,9 +112,10 @@ def parse(argv=None):
     ap.add_argument("--presets", type=int, default=1,
                     help="default invocation only (preset metric, one GPU): after the headline, run the other BASELINE.json configurations (c2, c3, "
                          "c4 as one rank of eight, c5) for a few steps each as child processes and add their figures to the line as `presets`")
-    ap.add_argument("--cpu-sample-classes", type=int, default=2, help="classes per CPU worker process and repetition (0: skip)")
+    ap.add_argument("--cpu-sample-classes", type=int, default=4, help="classes per CPU worker process and repetition (0: skip)")
     ap.add_argument("--cpu-threads", type=int, default=16, help="threads per CPU worker process")
-    ap.add_argument("--cpu-reps", type=int, default=3)
+    ap.add_argument("--cpu-reps", type=int, default=5, help="timed repetitions of the faster precision (fp32 math); the fp16 leg, 2-3x slower on "
+                    "these hosts, gets 2 -- enough to show it is the slower one")
     ap.add_argument("--cpu-procs", type=int, default=0, help="CPU worker processes (0: usable CPUs // --cpu-threads)")
     ap.add_argument("--cpu-timeout", type=float, default=240.0, help="give up on the CPU baseline after this many seconds")
     args = ap.parse_args(argv)
@@ -183,6 +186,11 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world, timeout=to)
         dist_info = process_group_identity(dist, dev, backend, world)
+
+    if PRESETS[args.preset].get("value") == "zeroshot":
+        assert world == 1 and not sharded, "--preset c1 is a one-GPU line (N ranks would run N replicas of the test loop)"
+        print(json.dumps(zeroshot_config(args, dev)), flush=True)
+        return
 
     out_dir = args.output_dir
     if out_dir == "tmpfs":
@@ -364,11 +372,12 @@ def run_presets(args):
     """The other BASELINE.json configurations on the same box, right behind the headline: each as a fresh child process of this script
     (its own weights, images and engine; this process has released its GPU memory), a few steps each.  Returns {preset: {value, unit,
     ms_per_step, steps, roofline_frac, workload}} -- or {"error": ...} for one that failed; the headline line does not depend on them."""
-    plan = (("c2", 3, 1), ("c3", 3, 1), ("c4", 2, 1), ("c5", 2, 1))
+    plan = (("c1", 3, 1), ("c2", 3, 1), ("c3", 3, 1), ("c4", 2, 1), ("c5", 2, 1))
     out = {}
     for name, steps, warm in plan:
-        cmd = [sys.executable, os.path.abspath(__file__), "--preset", name, "--steps", str(steps), "--warmup", str(warm), "--no-cpu-baseline",
+        cmd = [sys.executable, os.path.abspath(__file__), "--preset", name, "--steps", str(steps), "--warmup", str(warm),
                "--presets", "0", "--gelu-exact", str(args.gelu_exact), "--ln-fold", str(args.ln_fold)]
+        cmd += ["--cpu-reps", "3"] if name == "c1" and not args.no_cpu_baseline else ["--no-cpu-baseline"]
         t0 = time.perf_counter()
         try:
             r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
@@ -385,9 +394,102 @@ def run_presets(args):
                 out[name]["projection_excludes"] = d["projection"]["not_included"]
             if d.get("phases"):
                 out[name]["phases"] = {k: v for k, v in d["phases"].items() if k.endswith("images_per_s") or k.endswith("_rank0") or "xval" in k or "head" in k}
+            if name == "c1" and d.get("cpu_baseline"):       # configuration 1 is the reference's CPU-runnable case: its CPU figure belongs beside it
+                out[name]["cpu_baseline"] = {k: d["cpu_baseline"].get(k) for k in ("value", "unit", "cores", "kind", "sample", "fp32_images_per_s", "fp16_images_per_s")}
+                out[name]["gpu_over_cpu"] = d.get("gpu_over_cpu")
         except Exception as e:                               # noqa: BLE001
             out[name] = {"error": repr(e)[:300]}
     return out
+
+
+# ------------------------------------------------------------------------------------------
+def zeroshot_prompt_ids(num_classes, seed=4321, context_length=77):
+    """Tokenised `"a photo of a {}.".format(name)` prompts (trainers/zsclip.py:22, 42-45) with random class-name ids: [SOT, a, photo, of, a,
+    name tokens (1-3), ".", EOT, 0 ...] -- the ids the reference's tokenizer gives those words (tests/golden/c1_zeroshot.npz holds real ones)."""
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    ids = np.zeros((num_classes, context_length), dtype=np.int64)
+    for c in range(num_classes):
+        name = rng.integers(1000, 49000, size=int(rng.integers(1, 4)))
+        row = [49406, 320, 1125, 539, 320, *name.tolist(), 269, 49407]
+        ids[c, :len(row)] = row
+    return ids
+
+
+def zeroshot_config(args, dev):
+    """BASELINE.json configuration 1: ZeroshotCLIP (trainers/zsclip.py:32-60) on ViT-B/16, 10 classes.  One step = the text features of the ten
+    prompts (:47-50) + the whole test loop (Dassl.pytorch/dassl/engine/trainer.py:461-482) over --queries resident images in batches of
+    --query-batch: model_inference (:55-60: encode, normalise, scaled product -> raw fp16 logits) two batches in flight, every batch's
+    logits counted by the on-device evaluator (ovmr_eval_counts: no host round trip per batch), then evaluate() -- accuracy / macro-F1 from
+    the 3 C integers.  value = test images / s.  The CPU leg is the oracle's zeroshot_logits in fp32 (what clip.load gives a CPU device,
+    clip/clip.py:130-131) and in fp16, faster one reported."""
+    import torch
+    from ovmr_amd import modules, synth
+    from ovmr_amd.evaluator import Classification
+    spec = synth.SPECS[args.model]
+    C, Q, R = args.classes, args.queries, spec.image_resolution
+    gen = torch.Generator(device=dev).manual_seed(1234)
+    sd = device_clip_state(spec, gen, dev)
+    cm = modules.CLIPModel(sd, spec, str(dev))
+    ids = torch.from_numpy(zeroshot_prompt_ids(C))
+    zs = modules.ZeroshotCLIP(cm, ids, reserve=(args.query_batch, 256, max(C, 1024)))
+    eng = zs.engine
+    for k, v in (("gelu_exact", args.gelu_exact), ("fuse_im2col", args.fuse_im2col), ("enc_chunk", args.enc_chunk), ("last_q_cls", args.last_q_cls),
+                 ("gemm", args.gemm), ("attn", args.attn), ("ln_fold", args.ln_fold)):
+        eng.set_option(k, v)
+    ig = torch.Generator(device=dev).manual_seed(1234)
+    q_img = torch.empty((Q, 3, R, R), dtype=torch.float16, device=dev)
+    for s0 in range(0, Q, 1024):
+        q_img[s0:s0 + 1024] = torch.randn((min(1024, Q - s0), 3, R, R), generator=ig, device=dev).half()
+    labels = torch.randint(0, C, (Q,), generator=ig, device=dev)
+    ev = Classification(C, device=str(dev))
+    two = args.overlap == 1 or (args.overlap < 0 and args.query_batch <= zs.OVERLAP_MAX_BATCH)
+    if two:
+        zs._twin()
+    ids_dev = ids.to(dev)
+
+    def step():
+        zs.text_features = eng.encode_text_ids(ids_dev, normalize=1)              # :47-50
+        ev.reset()
+        b = 0
+        for out in zs.inference_batches((q_img[i:i + args.query_batch] for i in range(0, Q, args.query_batch)), stable_inputs=True,
+                                        overlap=None if args.overlap < 0 else bool(args.overlap)):
+            ev.process(out, labels[b:b + out.shape[0]])
+            b += out.shape[0]
+        return ev.counts()                                                          # the pass's one host read: 3 C + 1 integers
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        tp, n_pred, n_label = step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    assert int(n_label.sum()) == Q and int(n_pred.sum()) == Q
+    value = Q * args.steps / dt
+    roof = measure_roofline(eng, spec, args, dev, 0, Q)
+    cpu = None
+    if not args.no_cpu_baseline and args.cpu_sample_classes > 0:
+        cpu = cpu_baseline_zeroshot(spec, sd, ids, args)
+    flops_img = eng.flops_per_image()
+    fl = sum(eng.flops_executed(min(args.query_batch, Q - s0)) for s0 in range(0, Q, args.query_batch)) / Q
+    line = {"metric": f"images/sec, BASELINE.json configuration c1: {PRESETS['c1']['about']}",
+            "value": round(value, 2), "unit": "images/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1000 * dt / args.steps, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f16",
+            "data": "synthetic",
+            "config": {"workload": f"zero-shot CLIP test pass (trainers/zsclip.py), {args.model}, {C} prompts 'a photo of a <name>.', {Q} test images "
+                                   f"(batch {args.query_batch}), text features + logits + on-device evaluator inside the step",
+                       "parallelism": "one GPU", "preset": "c1", "gemm_variant": args.gemm, "attn_variant": args.attn, "ln_fold": args.ln_fold,
+                       "gelu_exact": args.gelu_exact, "images_per_step": Q, "inference_batches_in_flight": 2 if two else 1},
+            "roofline": roof, "cpu_baseline": cpu,
+            "phases": {"inference_images_per_s": round(value, 1), "encoder_tflops_e2e_algorithmic": round(value * flops_img / 1e12, 1),
+                       "encoder_tflops_e2e_executed": round(value * fl / 1e12, 1), "e2e_frac_of_fp16_mfma_peak": round(value * fl / 1e12 / 2500.0, 4),
+                       "accuracy_of_random_labels": round(100.0 * float(tp.sum()) / Q, 2)}}
+    if cpu and cpu.get("value"):
+        line["gpu_over_cpu"] = round(value / cpu["value"], 1)
+        line["gpu_over_cpu_note"] = f"1 GPU vs {cpu['cores']} CPU threads (of {cpu.get('host_cores')} on the host)"
+    return line
 
 
 def make_model(args, dev, sharded=False, output_dir=""):
@@ -642,10 +744,15 @@ def emulate_world(args, model, spec, dev):
                          "classifiers_fusion_weights_outputs_bit_equal_to_whole_job": bool(same), "bit_equal": eq,
                          "max_abs_diff_of_own_rows": worst})
     model._dist, model._text_streamed = None, bool(args.stream_text)
+    # the whole job once more, BEHIND the shards: the part runs its first seconds of a process faster than its steady state (clocks settle
+    # under load), so a numerator timed only in front of the shards flatters... the numerator.  Both are reported; the ratio uses their mean
+    t1_after = timed(whole)
+    t1_first, t1 = t1, 0.5 * (t1 + t1_after)
     worst = max(p["ms_per_step"] for p in per_rank)
     line = {"metric": f"PROJECTION of {N}-rank strong scaling from one MI355X: every rank's shard timed alone, no process group, no xGMI traffic",
             "projection": True, "emulated_world": N, "ranks_timed": [p["rank"] for p in per_rank],
-            "whole_job_ms_one_rank": round(1000 * t1, 3), "whole_job_images_per_s": round((C * S + Q) / t1, 1),
+            "whole_job_ms_one_rank": round(1000 * t1, 3), "whole_job_ms_timed_before_the_shards": round(1000 * t1_first, 3),
+            "whole_job_ms_timed_after_the_shards": round(1000 * t1_after, 3), "whole_job_images_per_s": round((C * S + Q) / t1, 1),
             "slowest_rank_ms": worst, "projected_speedup": round(1000 * t1 / worst, 3),
             "projected_images_per_s": round((C * S + Q) / (worst / 1000), 1),
             "not_included": "the RCCL all-gather of the packed rows and the all-reduce of the counters over xGMI (here: device copies of the "
@@ -657,7 +764,7 @@ def emulate_world(args, model, spec, dev):
     return line
 
 
-def shard_of_world(args, model, spec, dev, keep=None):
+def shard_of_world(args, model, spec, dev, keep=None, peers=None):
     """BASELINE.json configuration 4 as ONE rank of `--emulate-world` ranks, for a job whose exemplar set does not fit one GPU's turn
     (10 000 classes x 64 shots = 640 000 images = 193 GB of fp16 pixels): every rank's exemplars are drawn into ONE reusable buffer
     (seed 1234 + rank, as the N-rank job draws them) and run through hot loop A once, untimed, to record that rank's packed classifier
@@ -665,7 +772,10 @@ def shard_of_world(args, model, spec, dev, keep=None):
     Then rank `--emulate-rank` is timed through the SHARDED code path (CustomCLIP.forward_prompt with the two collectives served from the
     recorded blocks and votes) plus its share of the queries.  The line's value is that rank's measured images/s on this GPU;
     `projection` holds the N-rank figure (total images / this rank's time), which excludes xGMI, barrier skew and start-up.
-    keep: a dict that receives the tensors behind the line (tests/test_hip_configs.py checks them against the oracle)."""
+    keep: a dict that receives the tensors behind the line (tests/test_hip_configs.py checks them against the oracle).
+    peers: None = every other rank's exemplars go through the encoder (the bench preset); a list = only those ranks' do, the remaining
+    ranks contribute unit-norm random rows and features under their own class labels (the GPU test: what it probes on those ranks is the
+    all-gather, the votes and the counters, not the encoder a third time -- 120 960 instead of 322 560 images at 5 040 classes)."""
     import torch
     from ovmr_amd.data import ResidentEvalSet
     from ovmr_amd.shard import shard_range, pack_block, local_class_bound
@@ -694,6 +804,17 @@ def shard_of_world(args, model, spec, dev, keep=None):
         model._reset_generation_state()
         blocks = [None] * N
         for r in [x for x in range(N) if x != R0] + [R0]:
+            if peers is not None and r != R0 and r not in peers:
+                a0, a1 = shard_range(C, r, N)
+                loc = torch.arange(a0, a1, device=dev)
+                sg = torch.Generator(device=dev).manual_seed(99 + r)
+                unit = lambda *shape: torch.nn.functional.normalize(torch.randn(shape, generator=sg, device=dev), dim=-1).half()
+                model.mm_classifier[loc], model.visual_classifer[loc], model._text_rows[loc] = unit(a1 - a0, D), unit(a1 - a0, D), unit(a1 - a0, D)
+                model.visual_tokens[loc] = torch.randn((a1 - a0, n_ctx, D), generator=sg, device=dev).half()
+                model.eval_feat4cls[loc] = unit(a1 - a0, S, D)
+                blocks[r] = pack_block(torch.cat([model.mm_classifier[loc], model.visual_classifer[loc], model._text_rows[loc],
+                                                  model.visual_tokens[loc].flatten(1)], dim=1), loc, bound)
+                continue
             loader, q = draw(r)
             loc = model._generate_local(loader)
             blocks[r] = pack_block(torch.cat([model.mm_classifier[loc], model.visual_classifer[loc], model._text_rows[loc],
@@ -985,10 +1106,12 @@ def pmc_traffic(variant, M, N, batch, epi=2):
     return {"traffic": None, "kernel_source_sha16": sha}
 
 
-def _cpu_worker(widx, nproc, threads, spec_name, sd16, pl, tok, shots, classes, reps, n_ctx, barrier, queue):
-    """One CPU worker: `classes` classes x `shots` exemplars of its own slice through the oracle's forward_prompt + fused
-    inference on 4 queries, 1 warm-up + `reps` timed repetitions in fp32 (what the reference computes after clip_model.float())
-    and the same in fp16 (the precision its OVMR path runs in as shipped).  All workers start each repetition together."""
+def _cpu_worker(widx, nproc, threads, spec_name, sd16, pl, tok, shots, classes, reps, n_ctx, barrier, queue, kind="ovmr"):
+    """One CPU worker.  kind "ovmr": `classes` classes x `shots` exemplars of its own slice through the oracle's forward_prompt + fused
+    inference on 4 queries; kind "zeroshot": the oracle's zeroshot_logits (trainers/zsclip.py:55-60) on `classes` x `shots` images against
+    the prompts' text features (encoded once per repetition).  1 warm-up + reps[0] timed repetitions in fp32 (what the reference computes
+    after clip_model.float()) and 1 + reps[1] in fp16 (the precision its OVMR path runs in as shipped).  All workers start each repetition
+    together."""
     import torch
     from oracle import ovmr_oracle as O
     from ovmr_amd import synth
@@ -1000,9 +1123,14 @@ def _cpu_worker(widx, nproc, threads, spec_name, sd16, pl, tok, shots, classes, 
     img = torch.randn((classes * shots, 3, R, R), generator=g)
     q = torch.randn((4, 3, R, R), generator=g)
     labels = torch.arange(classes).repeat_interleave(shots)
-    mytok = tok[widx * classes:(widx + 1) * classes]
+    mytok = tok[widx * classes:(widx + 1) * classes] if kind == "ovmr" else tok
 
     def job(sd, prec, x, qx):
+        if kind == "zeroshot":
+            tf = O.l2_normalize(O.encode_text(mytok, sd))
+            for s0 in range(0, x.shape[0], 32):
+                O.zeroshot_logits(x[s0:s0 + 32], tf, sd)
+            return
         r = O.forward_prompt(x, labels, mytok, sd, pl, n_ctx, 10.0, max(1, 64 // shots), prec)
         qf = O.l2_normalize(O.encode_image(qx, sd))
         O.inference_logits(qf, r["mm_classifier"].to(qf.dtype), r["vision_classifier"].to(qf.dtype), r["text_classifier"].to(qf.dtype),
@@ -1010,8 +1138,8 @@ def _cpu_worker(widx, nproc, threads, spec_name, sd16, pl, tok, shots, classes, 
 
     times32, times16 = [], []
     with torch.no_grad():
-        for sdx, prec, x, qx, out in ((sd32, "fp32", img, q, times32), (sd16, "fp16", img.half(), q.half(), times16)):
-            for rep in range(reps + 1):                              # rep 0 = warm-up
+        for sdx, prec, x, qx, out, n in ((sd32, "fp32", img, q, times32, reps[0]), (sd16, "fp16", img.half(), q.half(), times16, reps[1])):
+            for rep in range(n + 1):                                 # rep 0 = warm-up
                 barrier.wait(timeout=600)
                 t0 = time.perf_counter()
                 job(sdx, prec, x, qx)
@@ -1043,13 +1171,13 @@ def effective_cpus():
     return n, quota
 
 
-def cpu_baseline(spec, sd, pl, tok, args, n_ctx):
+def cpu_baseline(spec, sd, pl, tok, args, n_ctx, kind="ovmr"):
     """The oracle (torch-CPU port of the reference path) on the CPUs THIS PROCESS MAY USE -- the affinity mask capped by the cgroup
     quota (`effective_cpus`: 16 of the 256 hardware threads on the GPU boxes), not the whole host: usable // threads worker processes x
     `--cpu-threads` threads (a single 256-thread pool is far slower than 16-thread pools on this path), disjoint class slices of
-    `--cpu-sample-classes` classes x shots (batch 32 at the defaults), 1 warm-up + `--cpu-reps` timed repetitions, median.
-    images/s = sum over workers of images per repetition / median repetition time, all workers running together.
-    Reported: the faster of fp32-math-on-fp16-rounded-weights and fp16."""
+    `--cpu-sample-classes` classes x shots (64 images + 4 queries at the defaults), 1 warm-up + `--cpu-reps` timed repetitions in fp32
+    and 1 + 2 in fp16.  images/s of a repetition = sum over workers of images / that repetition's time, all workers running together;
+    value = the MEDIAN repetition of the faster precision, min / max beside it."""
     import statistics
     import torch
     import torch.multiprocessing as mp
@@ -1060,15 +1188,17 @@ def cpu_baseline(spec, sd, pl, tok, args, n_ctx):
     if args.cpu_procs > 0:
         nproc = args.cpu_procs
     S, Cs = args.shots, args.cpu_sample_classes
+    reps = (max(1, args.cpu_reps), max(1, min(2, args.cpu_reps)))
     sd16 = O.convert_weights({k: v.detach().float().cpu() for k, v in sd.items()}, "fp16")
     for v in sd16.values():
         v.share_memory_()
-    cpu_pl = {k: v.detach().float().cpu().share_memory_() for k, v in pl.items()}
+    cpu_pl = {k: v.detach().float().cpu().share_memory_() for k, v in (pl or {}).items()}
     ctx = mp.get_context("spawn")                                  # this process has initialised the GPU: no fork
     barrier, queue = ctx.Barrier(nproc), ctx.Queue()
     t_all = time.perf_counter()
-    procs = [ctx.Process(target=_cpu_worker, args=(i, nproc, threads, spec.name, sd16, cpu_pl, tok[:nproc * Cs].clone(), S, Cs,
-                                                   args.cpu_reps, n_ctx, barrier, queue)) for i in range(nproc)]
+    wtok = tok[:nproc * Cs].clone() if kind == "ovmr" else tok.clone()
+    procs = [ctx.Process(target=_cpu_worker, args=(i, nproc, threads, spec.name, sd16, cpu_pl, wtok, S, Cs, reps, n_ctx, barrier, queue, kind))
+             for i in range(nproc)]
     saved_env = {k: os.environ.get(k) for k in ("OMP_NUM_THREADS", "MKL_NUM_THREADS")}
     os.environ.update(OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads))   # children size their pools at import
     try:
@@ -1097,25 +1227,38 @@ def cpu_baseline(spec, sd, pl, tok, args, n_ctx):
     for p in procs:
         p.join(timeout=30)
     t_all = time.perf_counter() - t_all
-    n_img = Cs * S + 4
-    per32 = [n_img / statistics.median(t) for _, t, _ in res]
-    per16 = [n_img / statistics.median(t) for _, _, t in res]
-    v32, v16 = sum(per32), sum(per16)
+    n_img = Cs * S + (4 if kind == "ovmr" else 0)
+    # per repetition: all workers' images over that repetition's time on each worker (they start it together)
+    rate32 = [sum(n_img / t32[r] for _, t32, _ in res) for r in range(reps[0])]
+    rate16 = [sum(n_img / t16[r] for _, _, t16 in res) for r in range(reps[1])]
+    v32, v16 = statistics.median(rate32), statistics.median(rate16)
+    best, best_name = (rate32, "fp32 math on fp16-rounded weights") if v32 >= v16 else (rate16, "fp16")
     model = "unknown"
     try:
         with open("/proc/cpuinfo") as f:
             model = next(l.split(":", 1)[1].strip() for l in f if l.startswith("model name"))
     except Exception:
         pass
+    what = (f"{Cs} class(es) x {S} shots generation + 4 fusion queries ({n_img} images) on its own class slice" if kind == "ovmr" else
+            f"zero-shot logits (trainers/zsclip.py:55-60) of {n_img} images in batches of 32 against {tok.shape[0]} prompts' text features")
     return {"value": round(max(v16, v32), 2), "unit": "images/s", "cores": nproc * threads, "kind": "port",
-            "sample": f"{nproc} worker processes x {threads} threads, each {Cs} class(es) x {S} shots generation + 4 fusion queries "
-                      f"(batch {Cs * S}) on its own class slice, 1 warm-up + {args.cpu_reps} timed repetitions, median; "
-                      f"{nproc * threads} threads = the {cores} CPUs this process may use (cgroup quota) of {os.cpu_count()} host threads: "
-                      f"fp32 math on fp16-rounded weights {v32:.1f} img/s, fp16 {v16:.1f} img/s, faster reported; "
+            "min": round(min(best), 2), "median": round(statistics.median(best), 2), "max": round(max(best), 2), "repetitions": len(best),
+            "precision_reported": best_name,
+            "sample": f"{nproc} worker processes x {threads} threads, each {what}, 1 warm-up + {reps[0]} timed repetitions in fp32 / {reps[1]} in fp16, "
+                      f"median repetition; {nproc * threads} threads = the {cores} CPUs this process may use (cgroup quota) of {os.cpu_count()} host threads: "
+                      f"fp32 math on fp16-rounded weights {v32:.1f} img/s (min {min(rate32):.1f}, max {max(rate32):.1f}), fp16 {v16:.1f} img/s, faster reported; "
                       f"{t_all:.0f} s wall incl. process start",
             "host_cores": os.cpu_count(), "usable_cpus": cores, "cgroup_cpu_quota": quota, "cpu_model": model, "processes": nproc, "threads_per_process": threads,
-            "per_process_images_per_s": round(statistics.median(per32 if v32 >= v16 else per16), 3),
-            "fp16_images_per_s": round(v16, 2), "fp32_images_per_s": round(v32, 2)}
+            "fp16_images_per_s": round(v16, 2), "fp32_images_per_s": round(v32, 2),
+            "fp32_repetitions_images_per_s": [round(x, 2) for x in rate32], "fp16_repetitions_images_per_s": [round(x, 2) for x in rate16]}
+
+
+def cpu_baseline_zeroshot(spec, sd, ids, args):
+    """Configuration 1's CPU leg: the oracle's zeroshot_logits on `--cpu-sample-classes` x 16 images per worker (64 at the default)."""
+    import copy
+    a = copy.copy(args)
+    a.shots = 16
+    return cpu_baseline(spec, sd, None, ids, a, 2, kind="zeroshot")
 
 
 if __name__ == "__main__":

@@ -252,6 +252,105 @@ class PromptLearner:
     __call__ = forward
 
 
+# ----------------------------------------------------------------------------- two test batches in flight
+class _TwoInFlight:
+    """The model calls of an evaluation loop, software-pipelined over two handles / two streams (CustomCLIP.forward_batches,
+    ZeroshotCLIP.inference_batches).  A user defines `engine`, `device`, `_forward_on(engine, image[, out])` and `_twin_state()`."""
+
+    OVERLAP_MAX_TILES = 1024      # two batches in flight while the narrowest GEMM grid of ONE batch (ceil(rows / 256) x width / 256
+                                  # workgroups of 256 x 256) stays within 4 rounds of the 256 CUs; beyond that a batch's partial last round is
+                                  # a small share and two batches only contend (profiles/r03u_two_stream_sweep.log: ViT-B/16 128 / 256 / 384
+                                  # images +26 / +7 / +4 %, 512 -2 %; ViT-L/14@336px 64 images +8 %, 128 -1 %, 256 -2 %)
+
+    @property
+    def OVERLAP_MAX_BATCH(self) -> int:
+        """Images per batch up to which forward_batches keeps two batches in flight (settable; default from OVERLAP_MAX_TILES:
+        ViT-B/16 443 images, ViT-L/14@336px 113)."""
+        if getattr(self, "_overlap_max_batch", None) is not None:
+            return self._overlap_max_batch
+        sp = self.engine.spec
+        tokens = (sp.image_resolution // sp.vision_patch_size) ** 2 + 1
+        row_tiles = self.OVERLAP_MAX_TILES // max(1, sp.vision_width // 256)
+        return max(1, row_tiles * 256 // tokens)
+
+    @OVERLAP_MAX_BATCH.setter
+    def OVERLAP_MAX_BATCH(self, n: int):
+        self._overlap_max_batch = int(n)
+
+    def _twin(self) -> Engine:
+        """A second handle: the same weights and options, its own workspace (sized for OVERLAP_MAX_BATCH images), used from
+        a second stream.  Rebuilt when the first handle's weights have changed since."""
+        e = self.engine
+        t = getattr(self, "_twin_engine", None)
+        if t is None or t._twin_of_version != e._weights_version:
+            t = Engine(e.spec, e.n_ctx, str(e.device))
+            t.load_state_dict(*self._twin_state())
+            t._pl_loaded = True
+            res = getattr(e, "_reserve", (256, 256, 1024))
+            t._reserve = (min(res[0], self.OVERLAP_MAX_BATCH), res[1], res[2])
+            t._twin_of_version = e._weights_version
+            self._twin_engine = t
+        for k, v in e._options.items():
+            if t._options.get(k) != v:
+                t.set_option(k, v)
+        return _ensure_final(t)
+
+    def _run_batches(self, batches, overlap, stable_inputs):
+        cur = torch.cuda.current_stream(self.device)
+
+        def hand_over(p):
+            out, ev = p
+            cur.wait_event(ev)
+            out.record_stream(cur)
+            return out
+
+        cap = min(self.OVERLAP_MAX_BATCH, getattr(self.engine, "_reserve", (256,))[0])    # what the twin's workspace holds
+        try:
+            yield from self._forward_batches(batches, overlap, stable_inputs, cap, cur, hand_over)
+        finally:                                         # also when the caller abandons the loop: later work on the caller's stream
+            for st in getattr(self, "_overlap_streams", ()):     # (another forward on the first handle) is ordered behind what is in flight
+                cur.wait_stream(st)
+
+    def _forward_batches(self, batches, overlap, stable_inputs, cap, cur, hand_over):
+        pending = None                                   # (output, event on its stream)
+        k = 0
+        for image in batches:
+            image = self.engine._dev(image)
+            use = overlap if overlap is not None else image.shape[0] <= cap
+            if not use or image.shape[0] > cap:
+                if pending is not None:
+                    yield hand_over(pending)
+                    pending = None
+                yield self._forward_on(self.engine, image)
+                continue
+            if not hasattr(self, "_overlap_streams"):
+                self._overlap_streams = [torch.cuda.Stream(self.device), torch.cuda.Stream(self.device)]
+                self._overlap_staging = [None, None]
+            eng = self.engine if (k & 1) == 0 else self._twin()
+            st = self._overlap_streams[k & 1]
+            if not stable_inputs:                        # (the previous user of this staging buffer, batch k - 2, was handed over already:
+                buf = self._overlap_staging[k & 1]       #  the current stream is ordered behind it)
+                if buf is None or buf.shape[1:] != image.shape[1:] or buf.shape[0] < image.shape[0] or buf.dtype != image.dtype:
+                    buf = self._overlap_staging[k & 1] = torch.empty((cap,) + tuple(image.shape[1:]),
+                                                                     dtype=image.dtype, device=self.device)
+                staged = buf[:image.shape[0]]
+                staged.copy_(image)
+                image = staged
+            st.wait_stream(cur)
+            with torch.cuda.stream(st):
+                out = self._forward_on(eng, image)
+                ev = torch.cuda.Event()
+                ev.record(st)
+            if stable_inputs:
+                image.record_stream(st)
+            if pending is not None:
+                yield hand_over(pending)
+            pending = (out, ev)
+            k += 1
+        if pending is not None:
+            yield hand_over(pending)
+
+
 # ----------------------------------------------------------------------------- CustomCLIP
 class _ImageEncoder:
     """clip_model.visual as CustomCLIP uses it: callable, with .output_dim (:184, :216)."""
@@ -264,7 +363,7 @@ class _ImageEncoder:
         return self.engine.encode_image(image, normalize=False)
 
 
-class CustomCLIP:
+class CustomCLIP(_TwoInFlight):
     """trainers/mm_classifier_one_prompt.py:179-364 (evaluation / classifier-generation branch)."""
 
     def __init__(self, cfg, classnames, clip_model: CLIPModel, tokenizer=None,
@@ -307,6 +406,9 @@ class CustomCLIP:
 
     def eval(self):
         return self
+
+    def _twin_state(self):
+        return self.prompt_learner.clip_model.state_dict(), self.prompt_learner.state_dict()
 
     # :200-212
     def get_mm_v_feats(self, mm_prompts, mm_lens, v_prompts, v_lens, text_ids=None):
@@ -593,45 +695,6 @@ class CustomCLIP:
         out.record_stream(st)
         return out
 
-    # ------------------------------------------------------------------ the test loop's forwards, two batches in flight
-    OVERLAP_MAX_TILES = 1024      # two batches in flight while the narrowest GEMM grid of ONE batch (ceil(rows / 256) x width / 256
-                                  # workgroups of 256 x 256) stays within 4 rounds of the 256 CUs; beyond that a batch's partial last round is
-                                  # a small share and two batches only contend (profiles/r03u_two_stream_sweep.log: ViT-B/16 128 / 256 / 384
-                                  # images +26 / +7 / +4 %, 512 -2 %; ViT-L/14@336px 64 images +8 %, 128 -1 %, 256 -2 %)
-
-    @property
-    def OVERLAP_MAX_BATCH(self) -> int:
-        """Images per batch up to which forward_batches keeps two batches in flight (settable; default from OVERLAP_MAX_TILES:
-        ViT-B/16 443 images, ViT-L/14@336px 113)."""
-        if getattr(self, "_overlap_max_batch", None) is not None:
-            return self._overlap_max_batch
-        sp = self.engine.spec
-        tokens = (sp.image_resolution // sp.vision_patch_size) ** 2 + 1
-        row_tiles = self.OVERLAP_MAX_TILES // max(1, sp.vision_width // 256)
-        return max(1, row_tiles * 256 // tokens)
-
-    @OVERLAP_MAX_BATCH.setter
-    def OVERLAP_MAX_BATCH(self, n: int):
-        self._overlap_max_batch = int(n)
-
-    def _twin(self) -> Engine:
-        """A second handle: the same weights and options, its own workspace (sized for OVERLAP_MAX_BATCH images), used from
-        a second stream.  Rebuilt when the first handle's weights have changed since."""
-        e = self.engine
-        t = getattr(self, "_twin_engine", None)
-        if t is None or t._twin_of_version != e._weights_version:
-            t = Engine(e.spec, e.n_ctx, str(e.device))
-            t.load_state_dict(self.prompt_learner.clip_model.state_dict(), self.prompt_learner.state_dict())
-            t._pl_loaded = True
-            res = getattr(e, "_reserve", (256, 256, 1024))
-            t._reserve = (min(res[0], self.OVERLAP_MAX_BATCH), res[1], res[2])
-            t._twin_of_version = e._weights_version
-            self._twin_engine = t
-        for k, v in e._options.items():
-            if t._options.get(k) != v:
-                t.set_option(k, v)
-        return _ensure_final(t)
-
     @torch.no_grad()
     def forward_batches(self, batches: Iterable, eval_set_loader=None, overlap: Optional[bool] = None, stable_inputs: bool = False):
         """The model calls of the evaluation loop (dassl's test(): one forward per test batch, trainers' model_inference),
@@ -650,74 +713,43 @@ class CustomCLIP:
             if eval_set_loader is None:
                 raise NotImplementedError("pass eval_set_loader= to generate the classifiers")
             self.forward_prompt(eval_set_loader, wait_files=False)
-        cur = torch.cuda.current_stream(self.device)
-
-        def hand_over(p):
-            out, ev = p
-            cur.wait_event(ev)
-            out.record_stream(cur)
-            return out
-
-        cap = min(self.OVERLAP_MAX_BATCH, getattr(self.engine, "_reserve", (256,))[0])    # what the twin's workspace holds
-        try:
-            yield from self._forward_batches(batches, overlap, stable_inputs, cap, cur, hand_over)
-        finally:                                         # also when the caller abandons the loop: later work on the caller's stream
-            for st in getattr(self, "_overlap_streams", ()):     # (another forward on the first handle) is ordered behind what is in flight
-                cur.wait_stream(st)
-
-    def _forward_batches(self, batches, overlap, stable_inputs, cap, cur, hand_over):
-        pending = None                                   # (output, event on its stream)
-        k = 0
-        for image in batches:
-            image = self.engine._dev(image)
-            use = overlap if overlap is not None else image.shape[0] <= cap
-            if not use or image.shape[0] > cap:
-                if pending is not None:
-                    yield hand_over(pending)
-                    pending = None
-                yield self._forward_on(self.engine, image)
-                continue
-            if not hasattr(self, "_overlap_streams"):
-                self._overlap_streams = [torch.cuda.Stream(self.device), torch.cuda.Stream(self.device)]
-                self._overlap_staging = [None, None]
-            eng = self.engine if (k & 1) == 0 else self._twin()
-            st = self._overlap_streams[k & 1]
-            if not stable_inputs:                        # (the previous user of this staging buffer, batch k - 2, was handed over already:
-                buf = self._overlap_staging[k & 1]       #  the current stream is ordered behind it)
-                if buf is None or buf.shape[1:] != image.shape[1:] or buf.shape[0] < image.shape[0] or buf.dtype != image.dtype:
-                    buf = self._overlap_staging[k & 1] = torch.empty((cap,) + tuple(image.shape[1:]),
-                                                                     dtype=image.dtype, device=self.device)
-                staged = buf[:image.shape[0]]
-                staged.copy_(image)
-                image = staged
-            st.wait_stream(cur)
-            with torch.cuda.stream(st):
-                out = self._forward_on(eng, image)
-                ev = torch.cuda.Event()
-                ev.record(st)
-            if stable_inputs:
-                image.record_stream(st)
-            if pending is not None:
-                yield hand_over(pending)
-            pending = (out, ev)
-            k += 1
-        if pending is not None:
-            yield hand_over(pending)
+        yield from self._run_batches(batches, overlap, stable_inputs)
 
 
-class ZeroshotCLIP:
-    """trainers/zsclip.py:32-60 (BASELINE config 1): prompts -> text features; raw logits."""
+class ZeroshotCLIP(_TwoInFlight):
+    """trainers/zsclip.py:32-60 (BASELINE config 1): prompts -> text features; raw logits.
+    `tokenized_prompts`: LongTensor [C, 77] -- clip.tokenize of CUSTOM_TEMPLATES[dataset].format(classname) (:42-45; tokenize() above with a
+    BPE tokenizer produces them from names)."""
 
-    def __init__(self, clip_model: CLIPModel, tokenized_prompts: torch.Tensor, n_ctx: int = 2):
+    def __init__(self, clip_model: CLIPModel, tokenized_prompts: torch.Tensor, n_ctx: int = 2, reserve=(256, 256, 1024)):
+        self.clip_model = clip_model
         self.engine = e = clip_model.engine(n_ctx)
-        if not hasattr(e, "_pl_loaded"):
-            e.load_state_dict({}, {k: torch.from_numpy(v) for k, v in
-                                   synth.prompt_learner_state_dict(clip_model.spec, n_ctx, 0).items()})
+        self.device = e.device
+        if not hasattr(e, "_pl_loaded"):                   # (the engine's handle also serves CustomCLIP: it wants the aggregator's weights)
+            self._pl_state = {k: torch.from_numpy(v) for k, v in synth.prompt_learner_state_dict(clip_model.spec, n_ctx, 0).items()}
+            e.load_state_dict({}, self._pl_state)
             e._pl_loaded = True
         if not e.finalized:
-            e.finalize(256, 256, 1024)
-        self.text_features = e.encode_text_ids(tokenized_prompts, normalize=1)      # :47-49
+            e._reserve = tuple(reserve)
+            e.finalize(*reserve)
+        self.tokenized_prompts = tokenized_prompts
+        self.text_features = e.encode_text_ids(tokenized_prompts, normalize=1)      # :47-50
+
+    def _twin_state(self):
+        pl = getattr(self, "_pl_state", None)
+        if pl is None:
+            pl = {k: torch.from_numpy(v) for k, v in synth.prompt_learner_state_dict(self.clip_model.spec, self.engine.n_ctx, 0).items()}
+        return self.clip_model.state_dict(), pl
+
+    def _forward_on(self, engine: Engine, image, out=None):
+        f = engine.encode_image(image, normalize=True)                              # :56-57
+        return engine.zeroshot_logits(f, self.text_features)                        # :58-59
 
     def model_inference(self, image):
-        f = self.engine.encode_image(image, normalize=True)                         # :56-57
-        return self.engine.zeroshot_logits(f, self.text_features)                   # :58-59
+        return self._forward_on(self.engine, image)
+
+    @torch.no_grad()
+    def inference_batches(self, batches: Iterable, overlap: Optional[bool] = None, stable_inputs: bool = False):
+        """model_inference for every image batch of the test loop (Dassl.pytorch/dassl/engine/trainer.py:461-482), in order and bit-identical
+        to calling it per batch, two batches in flight on two handles / streams (as CustomCLIP.forward_batches)."""
+        yield from self._run_batches(batches, overlap, stable_inputs)

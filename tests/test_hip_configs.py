@@ -220,8 +220,10 @@ def test_config_c4_vitb16_sixty_four_shots_one_rank_of_eight(O):
     """BASELINE.json configuration 4 on its own architecture: ViT-B/16, 64 shots (aggregator sequence 66 behind the real image
     tower), a 5040-class vocabulary (>= 5000: the reference leaves zero_shot_classifier = None at
     trainers/mm_classifier_one_prompt.py:118 and fails at :263-265), class-sharded over 8 ranks -- the job `bench.py --preset c4`
-    runs (bench.shard_of_world), at 5040 instead of 10 000 classes: all 8 ranks' exemplars (322 560 images, 630 classes each) go
-    through hot loop A, rank 0 then runs the SHARDED path with the peers' recorded rows and votes.  Checked:
+    runs (bench.shard_of_world), at 5040 instead of 10 000 classes: the exemplars of rank 0 and of two sampled peers (ranks 5 and 7: 120 960
+    images, 630 classes each; the bench preset and --emulate-world run all eight ranks' through the encoder) go through hot loop A, the
+    other five ranks contribute random unit rows and features under their own labels; rank 0 then runs the SHARDED path with the peers'
+    recorded rows and votes.  Checked:
       * rank 0 ends with the whole job's bits (rows, tokens, counters, fusion weights) -- asserted inside shard_of_world;
       * 3 sampled classes (2 of rank 0, 1 of rank 5): features, mm / vision / text rows, visual tokens against the oracle;
       * ALL 3 x 2 x 5040 counters of the whole job AND rank 0's own votes against the CPU restatement's bounds, 8 064 rows at a time
@@ -239,7 +241,10 @@ def test_config_c4_vitb16_sixty_four_shots_one_rank_of_eight(O):
     spec, sd, pl, tok, model = bench.make_model(args, dev)
     assert model.zero_shot_classifier is None or model._text_streamed
     keep = {}
-    line = bench.shard_of_world(args, model, spec, dev, keep)
+    # rank 0 (timed, through the sharded path) and two sampled peers (5: checked against the oracle below; 7: the last, ragged-free shard)
+    # run their exemplars through the encoder; the other five ranks contribute random unit rows / features under their own labels.  All
+    # eight ranks through the encoder, every one bit-equal to the whole job: bench.py --preset c4 and --emulate-world 8 (profiles/).
+    line = bench.shard_of_world(args, model, spec, dev, keep, peers=[5, 7])
     assert line["projection"]["projected"] and all(line["projection"]["rank_reproduces_whole_job_bits"].values())
     assert line["config"]["images_per_step"] == (C // N) * S + 2048 // N and line["value"] > 0
     ref, counts_full, feats = keep["ref"], keep["counts_full"].cpu().numpy(), keep["eval_feat4cls"]

@@ -485,3 +485,40 @@ def test_generate_classifier_script_maps_the_reference_arguments(tmp_path):
     env.pop("CLIP_WEIGHTS")
     r = subprocess.run(["bash", script, "imagenet", "1", "all", "2", "fusion", "10", "0"], env=env, capture_output=True, text=True)
     assert r.returncode != 0 and "CLIP_WEIGHTS" in r.stderr
+
+
+def test_eval_ovmr_script_maps_the_reference_directories(tmp_path):
+    """scripts/eval_ovmr.sh = the reference's scripts/mm_cls/eval_ovmr.sh:19-47: the same seven arguments and train.py flags as the generation
+    script, the generator's checkpoint read from the base-to-new training output (:27) and the results written under
+    base2new/test_<SUB>_<MODE>_tau<TAU>/<DATASET>/shots_16/MM_CLS_OP/<CFG>/seed<SEED> (:28); an existing result directory skips the job."""
+    import subprocess
+    from ovmr_amd import cli
+    script = os.path.join(REPO, "scripts", "eval_ovmr.sh")
+    env = dict(os.environ, DRY_RUN="1", CLIP_WEIGHTS="/w/ViT-B-16.pt", OVMR_REF="/ref")
+    for k in ("DIR", "MODEL_DIR", "CFG", "SHOTS"):
+        env.pop(k, None)
+    r = subprocess.run(["bash", script, "caltech101", "3", "new", "2", "fusion", "10", "0"], env=env, capture_output=True, text=True, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr
+    words = r.stdout.split("\n")[:-1]
+    assert words[:3] == ["python", "-m", "ovmr_amd.cli"]
+    a = cli.parse(words[3:])
+    cfgname = "vit_b16_c4_ep50_imagenet21k_pretrain"
+    assert a.model_dir == f"output_ovmr/base2new/train_base/imagenet_21k_P/shots_64/MM_CLS_OP/{cfgname}/seed1"
+    assert a.output_dir == f"output_ovmr/base2new/test_new_fusion_tau10/caltech101/shots_16/MM_CLS_OP/{cfgname}/seed3"
+    assert a.eval_only and a.load_epoch == 30 and a.seed == 3 and a.n_ctx == 2 and a.eval_mode == "fusion" and a.eval_tau == 10
+    assert a.dataset_config_file == "/ref/configs/datasets/caltech101.yaml" and a.config_file == f"/ref/configs/trainers/MM_CLS_OP/{cfgname}.yaml"
+    assert a.opts == ["DATASET.NUM_SHOTS", "16", "DATASET.SUBSAMPLE_CLASSES", "new"]
+    # the environment still wins over the script's directories; several GPUs -> one rank per GPU
+    r = subprocess.run(["bash", script, "caltech101", "3", "base", "2", "vision", "5", "0,1"], env=dict(env, MODEL_DIR="/ck", SHOTS="8"),
+                       capture_output=True, text=True, cwd=str(tmp_path))
+    assert r.returncode == 0 and r.stdout.startswith("ranks 2")
+    a = cli.parse(r.stdout.split("\n")[4:-1])
+    assert a.model_dir == "/ck" and "/shots_8/" in a.output_dir and "test_base_vision_tau5" in a.output_dir and a.opts[:2] == ["DATASET.NUM_SHOTS", "8"]
+    # an existing result directory skips the job (reference :30-31) -- without DRY_RUN, nothing else is started
+    done = tmp_path / "output_ovmr/base2new/test_new_fusion_tau10/caltech101/shots_16/MM_CLS_OP" / cfgname / "seed3"
+    done.mkdir(parents=True)
+    env2 = {k: v for k, v in env.items() if k != "DRY_RUN"}
+    r = subprocess.run(["bash", script, "caltech101", "3", "new", "2", "fusion", "10", "0"], env=env2, capture_output=True, text=True, cwd=str(tmp_path))
+    assert r.returncode == 0 and "results exist" in r.stdout
+    r = subprocess.run(["bash", script, "caltech101"], env=env, capture_output=True, text=True)
+    assert r.returncode == 2 and "usage" in r.stderr

@@ -62,6 +62,47 @@ def test_l1_vitb16(golden, prec):
     assert_cosine(tf.float().numpy(), g[f"l1_{prec}_text_features"], 2e-5, "text_features")
 
 
+@pytest.mark.parametrize("prec", ["fp16", "fp32"])
+def test_c1_zeroshot_ten_prompts(golden, prec):
+    """BASELINE.json configuration 1 (trainers/zsclip.py:32-60 on a 10-class Caltech-101 subset): the oracle's encode_text / zeroshot_logits on
+    the prompts the REAL clip.tokenize produced for "a photo of a {}." against the real CLIP module's text features and raw logits, in the
+    fp16 model and after .float() (clip/clip.py:130-131: what the reference runs on a CPU device).  First 6 of the 16 recorded images."""
+    g = golden("c1_zeroshot")
+    spec = synth.SPECS[str(g["c1_meta_spec"])]
+    sd = _sd(spec, prec)
+    ids = torch.from_numpy(g["c1_token_ids"])
+    assert ids.shape == (10, 77) and str(g["c1_prompts"][0]) == "a photo of a accordion."
+    img = torch.from_numpy(synth.images(int(g["c1_meta_n_img"]), spec.image_resolution, seed=int(g["c1_meta_img_seed"])))[:6]
+    with torch.no_grad():
+        tf = O.l2_normalize(O.encode_text(ids, sd))
+        zs = O.zeroshot_logits(img.to(tf.dtype), tf, sd)
+    assert_cosine(tf.float().numpy(), g[f"c1_{prec}_text_features"], 2e-5, "text features")
+    assert_cosine(zs.float().numpy(), g[f"c1_{prec}_logits"][:6], 1e-4, "logits")
+    np.testing.assert_allclose(zs.float().numpy(), g[f"c1_{prec}_logits"][:6], atol=0.02 if prec == "fp16" else 2e-3)
+
+
+@pytest.mark.parametrize("prec", ["fp16", "fp32"])
+def test_hot_trained_like_statistics(golden, prec):
+    """The `hot` case: the real clip/model.py on ViT-B/16 (12 blocks) whose weights carry trained-like statistics
+    (synth.trained_like_statistics: massive-activation channels, skewed LayerNorm gains, peaky attention, saturated QuickGELU inputs).
+    The oracle must follow the reference there too -- it is what the GPU tests of the big jobs compare with."""
+    g = golden("hot")
+    spec = synth.SPECS[str(g["hot_meta_spec"])]
+    sd_np = synth.clip_state_dict(spec, int(g["hot_meta_seed"]), jitter=True)
+    hot = synth.trained_like_statistics(sd_np, spec, int(g["hot_meta_stat_seed"]))
+    assert np.array_equal(hot, g["hot_channels"])
+    sd = O.convert_weights(O.to_torch(sd_np), "fp16")
+    if prec == "fp32":
+        sd = {k: v.float() for k, v in sd.items()}
+    n = 4
+    img = torch.from_numpy(synth.images(int(g["hot_meta_n_img"]), spec.image_resolution, seed=int(g["hot_meta_img_seed"]), class_ids=np.arange(8) % 4,
+                                        class_strength=float(g["hot_meta_strength"]), tile=int(g["hot_meta_tile"])))[:n]
+    with torch.no_grad():
+        f = O.encode_image(img.to(sd["visual.proj"].dtype), sd)
+    assert_cosine(f.float().numpy(), g[f"hot_{prec}_image_features"][:n], 2e-5, "image features under trained-like statistics")
+    assert np.abs(g[f"hot_{prec}_cls_stream"][:, hot]).min() > 15.0              # the massive channels are there, in the reference's own stream
+
+
 @pytest.mark.parametrize("key,name,tag,n_ctx", [("tiny", "tiny", "l2", 2), ("tiny", "tiny", "l2n1", 1),
                                                 ("small", "small", "l2", 2), ("vitb16", "ViT-B/16", "l2", 2)])
 def test_l2_prompt_learner_and_text_encoder(golden, key, name, tag, n_ctx):
