@@ -13,7 +13,9 @@
  *     what ovmr_finalize() sized the workspace for (larger batches are processed in chunks);
  *   - return value: 0 = ok, otherwise an OVMR_E_* code or a positive hipError_t;
  *     ovmr_last_error(h) returns a message for the last failure on that handle;
- *   - one handle per (device, model, stream user): thread-compatible, not thread-safe;
+ *   - one handle per (device, model, stream user): thread-compatible, not thread-safe.  Calls on ONE handle must be ordered on ONE
+ *     stream (or by events): the workspace and the device-side phase counters of ovmr_fused_logits belong to the handle, and two
+ *     launches on it in flight at once would corrupt both.  Concurrency = several handles (CustomCLIP.forward_batches uses two);
  *   - fp16 = IEEE binary16 ("half"), the reference's only working OVMR precision
  *     (configs/trainers/MM_CLS_OP/vit_b16_c4_ep50_imagenet21k_pretrain.yaml:42).
  */
@@ -181,6 +183,12 @@ int ovmr_fusion_weights(ovmr_handle* h, const int32_t* counts, const int32_t* n_
 int ovmr_fused_logits(ovmr_handle* h, const void* feats_f16, int B, const void* mm_f16,
                       const void* v_f16, const void* t_f16, const float* w_f32, int C, int mode,
                       float* out_f32, ovmr_stream stream);
+
+/* Which implementation ovmr_fused_logits runs for B query rows and C classes on this handle: 1 = the one-launch head, 0 = scale + GEMMs +
+ * softmax (-1: bad arguments / not finalized).  Both keep the reference's rounding points (:357-363) but sum K in different orders, so a
+ * logit may land on the neighbouring fp16 value: a caller that splits one batch over several calls and promises the unsplit call's bits
+ * (CustomCLIP.forward's two halves) splits only where the plan is the same. */
+int ovmr_head_plan(const ovmr_handle* h, int B, int C);
 
 /* ZeroshotCLIP.model_inference (trainers/zsclip.py:55-60): out [B,C] fp16 =
  * exp(logit_scale) * feats @ text_feats^T (raw logits). */

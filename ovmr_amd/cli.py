@@ -292,10 +292,14 @@ def main(argv=None) -> Dict[str, float]:
             args.device = f"cuda:{local}"
         torch.cuda.set_device(torch.device(args.device))
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # ranks > 0 wait in the closing barrier while rank 0 evaluates the whole test set alone: the collective timeout has to cover a test
+        # pass, not a collective (the backend's default of 10 minutes would abort the waiting ranks, and the launcher then rank 0)
+        import datetime
+        to = datetime.timedelta(seconds=float(os.environ.get("OVMR_DIST_TIMEOUT", 6 * 3600)))
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device(args.device))
+            dist.init_process_group("nccl", device_id=torch.device(args.device), timeout=to)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, timeout=to)
         own_group = True
     if seed >= 0:
         print(f"Setting fixed seed: {seed}")                  # train.py:157-159
@@ -334,7 +338,9 @@ def main(argv=None) -> Dict[str, float]:
         kw = dict(workers=workers, prefetch=args.prefetch, device=args.device, fast_decode=args.fast_decode, device_resize=not args.host_resize, **tfm)
         eval_loader = PipelinedFolderLoader(exemplars, batch // shots * shots, size, rank, world, len(classnames), **kw)
         test_loader = PipelinedFolderLoader(test_items, batch, size, **kw)
-        (test_loader if test_loader.bs >= eval_loader.bs else eval_loader).warm()   # the decode workers start while the engine takes the weights (one ring serves both)
+        # the decode workers start while the engine takes the weights; on rank 0 one ring (sized for the larger batch) serves both loaders,
+        # ranks > 0 never touch the test set: theirs is sized for the exemplar batches alone
+        (eval_loader if rank > 0 or eval_loader.bs > test_loader.bs else test_loader).warm()
     else:
         eval_loader = FolderLoader(exemplars, batch // shots * shots, size, rank, world, len(classnames), **tfm)
         test_loader = FolderLoader(test_items, batch, size, **tfm)

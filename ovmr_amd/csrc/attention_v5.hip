@@ -430,11 +430,11 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn_f16_v5(const half_t* __rest
                 const half8_t kf = *(const half8_t*)(smem + koff[ks] + st_off);
                 s0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], ks == 0 ? (FOLD ? cm : zero16) : s0, 0, 0, 0);
             }
-            const int thr = tail - 4 * h;                  // registers 0..7: keys (k & 3) + 8 (k >> 2) + 4 h
-            float mx = -INFINITY;
+            const int thr_k = tail - 4 * h;                // registers 0..7: keys (k & 3) + 8 (k >> 2) + 4 h  (NOT `thr`: that is the FOLD
+            float mx = -INFINITY;                          //  variant's float rescale threshold, which the test below must see)
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
-                s0[k] = ((k & 3) + 8 * (k >> 2) < thr) ? s0[k] : -INFINITY;
+                s0[k] = ((k & 3) + 8 * (k >> 2) < thr_k) ? s0[k] : -INFINITY;
                 mx = fmaxf(mx, s0[k]);
             }
             {

@@ -26,13 +26,21 @@
 //     more than one tile keeps the last one in registers and queues the earlier ones for recomputation in phase 2 (normally the
 //     grid equals the tile count, every workgroup is resident, takes exactly one tile, and the queue stays empty).  The counters
 //     live in device memory owned by the handle; the last workgroup to leave re-arms them -- nothing on the host, replayable from
-//     a hipGraph, safe with several handles / streams in flight;
+//     a hipGraph, safe with several handles in flight, each used from ONE stream at a time (the counters and the workspace belong to the
+//     handle: two launches on one handle must be stream-ordered -- include/ovmr_hip.h says so for every entry point);
 //   * raw mode (zero-shot CLIP, one classifier, fp16 logits out): one pass, no counters.
 #include "common.h"
 
 #include <algorithm>
+#ifdef OVMR_EXPERIMENTS
+#include <cstdlib>
+#endif
 
 namespace {
+
+#ifdef OVMR_EXPERIMENTS
+inline int exp_env(const char* name) { const char* e = getenv(name); return e ? atoi(e) : 0; }
+#endif
 
 typedef float float16_t __attribute__((ext_vector_type(16)));
 
@@ -53,8 +61,28 @@ __device__ __forceinline__ void astore(float* p, float v) { __hip_atomic_store(p
 __device__ __forceinline__ float aloadf(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ int aadd(int* p, int v) { return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
+// "This tile / unit is done" and "everything is done": the orderings of the device-wide phases.  The data they order (per-tile statistics,
+// merged statistics, the recompute queue) are written and read with agent-scope atomic accesses, which on gfx950 go to device-coherent
+// memory by themselves; the product build orders them against the counters the way the ISA does -- every thread drains its stores
+// (s_waitcnt vmcnt(0)), the workgroup meets at a barrier, one thread bumps the counter; readers spin on the counter, meet at a barrier,
+// then issue their loads -- with RELAXED atomics, i.e. without the cache-wide write-back / invalidate a release / acquire pair at agent
+// scope compiles to (buffer_wbl2 sc1 / buffer_inv sc1: measured 3 us of a 30 us launch at 1000 classes, 33 us at 10 000, round 5).
+// ACQREL = true is that formally ordered form (C++ memory model: release on the increments, acquire after the spins); the experiment
+// build selects it with OVMR_HEAD_ACQREL=1 so that its cost stays measurable (tools/head_bench.py --acqrel; profiles/r06*_head_acqrel.log)
+// and tools/race_screen.py screens the relaxed form the product ships.
+template <bool ACQREL>
+__device__ __forceinline__ void hf_signal(int* counter) {
+    if constexpr (ACQREL) __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    else aadd(counter, 1);
+}
+template <bool ACQREL>
+__device__ __forceinline__ void hf_wait(int* counter, int target) {
+    while (aload(counter) < target) __builtin_amdgcn_s_sleep(2);
+    if constexpr (ACQREL) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+}
+
 // BM: query rows per tile (32 or 64).  RAW: one classifier, fp16 logits out, no softmax.
-template <int BM, bool RAW>
+template <int BM, bool RAW, bool ACQREL = false>
 __global__ __launch_bounds__(256, 2) void head_fused_kernel(const half_t* __restrict__ feats, int B, int D, float scale,
                                                          const half_t* __restrict__ c0, const half_t* __restrict__ c1,
                                                          const half_t* __restrict__ c2, int n_mod, int C,
@@ -320,12 +348,11 @@ __global__ __launch_bounds__(256, 2) void head_fused_kernel(const half_t* __rest
             HF_STAMP(3);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every thread: its pairs (and the queue entry) have reached device-coherent memory ...
             __syncthreads();
-            if (tid == 0) aadd(sync + HF_DONE, 1);                    // ... before the tile counts as done
+            if (tid == 0) hf_signal<ACQREL>(sync + HF_DONE);          // ... before the tile counts as done
             held = t;
         }
         HF_STAMP(4);
-        if (tid == 0)
-            while (aload(sync + HF_DONE) < n_tiles) __builtin_amdgcn_s_sleep(2);
+        if (tid == 0) hf_wait<ACQREL>(sync + HF_DONE, n_tiles);
         __syncthreads();                                              // (the pairs are read with device-coherent loads: nothing to invalidate)
         HF_STAMP(5);
         if (Tc > HF_LOCAL_MERGE_MAX) {
@@ -366,10 +393,9 @@ __global__ __launch_bounds__(256, 2) void head_fused_kernel(const half_t* __rest
                 }
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();
-                if (tid == 0) aadd(sync + HF_DUTY_DONE, 1);
+                if (tid == 0) hf_signal<ACQREL>(sync + HF_DUTY_DONE);
             }
-            if (tid == 0)
-                while (aload(sync + HF_DUTY_DONE) < n_units) __builtin_amdgcn_s_sleep(2);
+            if (tid == 0) hf_wait<ACQREL>(sync + HF_DUTY_DONE, n_units);
             __syncthreads();
         }
         HF_STAMP(6);
@@ -403,13 +429,20 @@ int launch_one(const half_t* feats, int B, int D, float scale, const half_t* con
                float* out, half_t* raw_out, float* partial, float* merged, int* leftover, int* sync, int Tc, size_t lds, int max_grid, hipStream_t s) {
     const int Tr = (B + BM - 1) / BM, n_tiles = Tr * Tc;
     auto kern = head_fused_kernel<BM, RAW>;
-    static size_t lds_set[OVMR_MAX_DEVICES] = {};            // per instantiation and device: the largest dynamic LDS size granted so far
+#ifdef OVMR_EXPERIMENTS
+    static const bool acqrel = exp_env("OVMR_HEAD_ACQREL") == 1;      // the release / acquire form of the phase counters (A/B: its cost)
+    if (acqrel && !RAW) kern = head_fused_kernel<BM, RAW, true>;
+#endif
+    static size_t lds_set[OVMR_MAX_DEVICES] = {};            // per (BM, RAW) and device: the largest dynamic LDS size granted so far
     if (lds > 64 * 1024) {
         int dev = 0;
         HIP_CHECK_RET(hipGetDevice(&dev));
         if (dev < 0 || dev >= OVMR_MAX_DEVICES) return -100;
         if (lds > lds_set[dev]) {
             HIP_CHECK_RET(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+#ifdef OVMR_EXPERIMENTS
+            HIP_CHECK_RET(hipFuncSetAttribute((const void*)head_fused_kernel<BM, RAW, !RAW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+#endif
             lds_set[dev] = lds;
         }
     }

@@ -336,6 +336,14 @@ int run_text_group_chunked(ovmr_handle* h, const TextGroup& g, hipStream_t s) {
     return 0;
 }
 
+// ovmr_fused_logits: the one-launch head (head_fused.hip) or scale + GEMMs + softmax.  Up to 256 query rows at any class count, up to 512
+// rows x 2048 classes: every 64-row tile re-reads the classifier matrices, so beyond that the GEMM path's 256-row tiles win
+// (tools/head_bench.py); option fused_head = 2 takes the one-launch kernel at any size, 0 never.  The two sum K in different orders: a logit
+// may land on the neighbouring fp16 value, so callers that promise bit-equal rows for differently batched calls ask ovmr_head_plan.
+bool head_takes_one_launch(const ovmr_handle* h, int B, int C) {
+    return h->fused_head && (B <= 256 || (B <= 512 && C <= 2048) || h->fused_head == 2) && head_fused_ws_bytes(B, C) <= h->ws_bytes;
+}
+
 int check_text_call(ovmr_handle* h, int seq_len, int normalize) {
     if (normalize < 0 || normalize > 2) return OVMR_E_ARG;
     if (!h->finalized) return fail(h, OVMR_E_STATE, "ovmr_finalize() has not been called");
@@ -833,6 +841,11 @@ int ovmr_fusion_weights(ovmr_handle* h, const int32_t* counts, const int32_t* n_
     return 0;
 }
 
+int ovmr_head_plan(const ovmr_handle* h, int B, int C) {
+    if (!h || !h->finalized || B < 0 || C < 1) return -1;
+    return head_takes_one_launch(h, B, C) && h->d.embed_dim % 64 == 0 ? 1 : 0;
+}
+
 int ovmr_pack_rows(const void* mm, const void* v, const void* t, const void* tokens, const int64_t* labels, int n, int D, int n_ctx, int bound,
                    void* block, ovmr_stream stream) {
     if (bound == 0) return 0;
@@ -872,9 +885,7 @@ int ovmr_fused_logits(ovmr_handle* h, const void* feats_f16, int B, const void* 
         default: return fail(h, OVMR_E_ARG, "unknown eval mode %d", mode);
     }
     for (int m = 0; m < n_mod; ++m) if (!clf[m]) return fail(h, OVMR_E_ARG, "classifier %d is NULL for mode %d", m, mode);
-    // (up to 256 query rows at any class count, up to 512 rows x 2048 classes: every 64-row tile re-reads the classifier matrices, so
-    //  beyond that the GEMM path's 256-row tiles win -- tools/head_bench.py; option fused_head = 2 takes the one-launch kernel at any size)
-    if (h->fused_head && (B <= 256 || (B <= 512 && C <= 2048) || h->fused_head == 2) && head_fused_ws_bytes(B, C) <= h->ws_bytes) {
+    if (head_takes_one_launch(h, B, C)) {
         // one launch: scaled features staged once, the (up to) three products, both rounding points, softmax and weighted sum (head_fused.hip)
         const half_t* cl[3] = {(const half_t*)clf[0], n_mod > 1 ? (const half_t*)clf[1] : nullptr, n_mod > 2 ? (const half_t*)clf[2] : nullptr};
         const int rc = launch_head_fused((const half_t*)feats_f16, B, D, h->logit_scale_exp, cl, n_mod, C, mode == OVMR_MODE_FUSION ? w : nullptr,

@@ -128,6 +128,15 @@ class DeviceResizer:
             raise runtime.OvmrError(f"ovmr_resize_crop_u8 failed with {rc}")
 
 
+def _shm_free_bytes():
+    """Free bytes of the tmpfs behind multiprocessing.shared_memory (None where there is no /dev/shm to ask)."""
+    import shutil
+    try:
+        return int(shutil.disk_usage("/dev/shm").free)
+    except OSError:
+        return None
+
+
 class _Pool:
     """Decode workers + the shared, page-locked upload ring.  Kept alive between passes (module cache, torn down at exit or by
     close_pools()): spawning 8-16 interpreters and registering the ring costs ~0.3-0.5 s, a third of a 1000-image pass."""
@@ -141,6 +150,12 @@ class _Pool:
         self.chunk_bytes = self.chunk * ((self.cap + 15) // 16 * 16)
         self.slot_bytes = self.n_chunks * self.chunk_bytes
         nbytes = self.slots * self.slot_bytes
+        # SharedMemory only ftruncate()s, which tmpfs grants beyond its free space: a ring larger than /dev/shm would be found out by the
+        # workers, as SIGBUS on their first store into a page that cannot be backed (Docker's default /dev/shm is 64 MiB; this ring is
+        # 576 MiB at batch 256 x 3 slots x 768 KiB).  Ask first -- the caller (_pool) then halves the share per image.
+        free = _shm_free_bytes()
+        if free is not None and nbytes + (16 << 20) > free:
+            raise OSError(f"the upload ring needs {nbytes >> 20} MiB of /dev/shm, {free >> 20} MiB are free")
         self.shm = shared_memory.SharedMemory(create=True, size=nbytes)
         self.host = torch.from_numpy(np.ndarray((self.slots, self.slot_bytes), dtype=np.uint8, buffer=self.shm.buf))
         self.cudart = torch.cuda.cudart()
@@ -253,10 +268,11 @@ class PipelinedFolderLoader:
         while True:
             try:
                 return _get_pool((self.workers, self.prefetch, self.bs, self.size, cap, self.chunk, self.interpolation, self.fast))
-            except OSError:                          # /dev/shm too small for this ring: a smaller share per image (more host resizes)
+            except OSError as e:                     # /dev/shm too small for this ring: a smaller share per image (more host resizes)
                 crop = self.size * self.size * 3
                 if cap <= crop:
-                    raise
+                    raise OSError(f"{e}; even one {self.size} x {self.size} crop per image does not fit: use a smaller TEST.BATCH_SIZE, "
+                                  "--prefetch 2, --workers 0 (no ring), or a larger /dev/shm") from None
                 cap = max(crop, cap // 2)
 
     def __iter__(self):
@@ -312,7 +328,8 @@ class PipelinedFolderLoader:
                         dead = [p for p in procs if not p.is_alive()]
                         if dead:
                             raise RuntimeError(f"{len(dead)} decode worker(s) died (exit codes {[p.exitcode for p in dead]}) -- killed by the "
-                                               "kernel for memory, or a crash inside the image library") from None
+                                               "kernel for memory (-9), out of /dev/shm space behind the upload ring (-7, SIGBUS: "
+                                               f"{(_shm_free_bytes() or 0) >> 20} MiB free now), or a crash inside the image library") from None
                         if time.perf_counter() - tw > 600:
                             raise RuntimeError("decode workers made no progress for 600 s") from None
                         continue

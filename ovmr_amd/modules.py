@@ -653,7 +653,8 @@ class CustomCLIP(_TwoInFlight):
                                       "pass eval_set_loader= to generate the classifiers")
         if self.mm_classifier is None:                                              # :341-342 (the features of `image` do not depend on it)
             self.forward_prompt(eval_set_loader, wait_files=False)                  # the files land while this batch and the next ones run
-        if self.SPLIT_FORWARD and 2 * self.SPLIT_MIN_HALF <= image.shape[0] <= self._split_cap():
+        B = image.shape[0]
+        if self.SPLIT_FORWARD and 2 * self.SPLIT_MIN_HALF <= B <= self._split_cap() and self._split_keeps_bits(B):
             return self._forward_split(image)
         return self._forward_on(self.engine, image)
 
@@ -672,7 +673,15 @@ class CustomCLIP(_TwoInFlight):
     SPLIT_FORWARD = True          # forward(image) of an UNCHANGED test loop (one model(input) per batch, a host sync per batch): the batch's
     SPLIT_MIN_HALF = 64           # two halves run on two handles / streams, so that the partial last round of GEMM tiles of one half is filled
                                   # by the other's work -- what forward_batches does across batches, without asking the caller for the next batch.
-                                  # Same rows bit for bit (a row's arithmetic does not depend on its batch: tests/test_hip_configs.py).
+                                  # Same rows bit for bit: a row's arithmetic does not depend on its batch as long as the head takes the
+                                  # same implementation (_split_keeps_bits; tests/test_hip_configs.py).
+
+    def _split_keeps_bits(self, B: int) -> bool:
+        """The head runs as one launch or as GEMMs + softmax depending on the rows of a call (ovmr_head_plan), and the two may differ by one
+        fp16 step in a logit: forward() splits a batch only where both halves take the implementation the whole batch takes, so that
+        model(b), forward_batches and SPLIT_FORWARD = False agree bit for bit (e.g. 300 images against 10 000 classes run unsplit)."""
+        C, e, half = len(self.tokenized_prompts), self.engine, (B + 1) // 2
+        return e.head_plan(B, C) == e.head_plan(half, C) == e.head_plan(B - half, C)
 
     def _split_cap(self) -> int:
         return min(self.OVERLAP_MAX_BATCH, 2 * getattr(self.engine, "_reserve", (256,))[0])

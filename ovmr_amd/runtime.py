@@ -64,6 +64,7 @@ SIGNATURES = {
     "ovmr_pack_rows": (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p]),
     "ovmr_unpack_rows": (c_i, [c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p]),
     "ovmr_eval_counts": (c_i, [c_p, c_i, ctypes.c_long, c_p, c_i, c_i, c_p, c_p]),
+    "ovmr_head_plan": (c_i, [c_p, c_i, c_i]),
     "ovmr_zeroshot_logits": (c_i, [c_p, c_p, c_i, c_p, c_i, c_p, c_p]),
     "ovmr_logit_scale": (ctypes.c_float, [c_p]),
     "ovmr_preprocess_u8": (c_i, [c_p, c_i, c_i, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float), c_p, c_p]),
@@ -370,6 +371,10 @@ class Engine:
         self._ck(self.lib.ovmr_fused_logits(self.h, _ptr(feats), feats.shape[0], _ptr(cl[0]), _ptr(cl[1]), _ptr(cl[2]),
                                             _ptr(w), C, MODES[mode], _ptr(out), _stream()), "ovmr_fused_logits")
         return out
+
+    def head_plan(self, B: int, C: int) -> int:
+        """1: fused_logits runs the one-launch head for B rows x C classes, 0: the GEMM path (their logits may differ by one fp16 step)."""
+        return int(self.lib.ovmr_head_plan(self.h, int(B), int(C)))
 
     def zeroshot_logits(self, feats, text_feats) -> torch.Tensor:
         feats = self._dev(feats, torch.float16)

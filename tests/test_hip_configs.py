@@ -437,3 +437,42 @@ def test_forward_batches_equals_forward_with_two_batches_in_flight(tmp_path):
     got = [o.clone() for o in model.forward_batches(iter(chunks[:3]))]
     assert model._twin_engine is not twin_before
     assert all(torch.equal(a, b) for a, b in zip(got, want[:3]))
+
+
+def test_forward_split_keeps_the_unsplit_head_implementation():
+    """The head runs as ONE launch for up to 256 rows (512 rows up to 2048 classes) and as GEMMs + softmax beyond (ovmr_head_plan), and the
+    two may differ by one fp16 step in a logit.  forward() runs a batch's two halves on two handles only where both halves take the
+    implementation the whole batch takes: model(b) == forward with SPLIT_FORWARD = False == forward_batches' output, bit for bit, also for
+    300 images against 2500 classes (whole batch: GEMM path; its halves alone would take the one-launch kernel) -- and the split still
+    happens, with the same bits, where the plan agrees (300 images against 1000 classes)."""
+    from ovmr_amd import modules
+    spec, sd, pl, cm = _small_clip("tiny")
+    B, D = 300, spec.embed_dim
+    g = torch.Generator(device="cuda").manual_seed(8)
+    q = torch.randn((B, 3, spec.image_resolution, spec.image_resolution), generator=g, device="cuda").half()
+    for C, splits in ((2500, False), (1000, True)):
+        tok = torch.from_numpy(synth.class_token_ids(C, seed=9))
+        cfg = modules.make_cfg(n_ctx=2, num_shots=2, output_dir="")
+        model = modules.CustomCLIP(cfg, tok, cm, prompt_learner_state={k: torch.from_numpy(x) for k, x in pl.items()}, reserve=(B, 64, C),
+                                   stream_text=True)
+        unit = lambda: torch.nn.functional.normalize(torch.randn((C, D), generator=g, device="cuda"), dim=-1).half()
+        model.mm_classifier, model.visual_classifer, model.zero_shot_classifier = unit(), unit(), unit()
+        model.fusion_weight = torch.softmax(torch.randn((C, 3), generator=g, device="cuda"), -1)
+        e = model.engine
+        assert (e.head_plan(B, C), e.head_plan(B // 2, C)) == ((0, 1) if C == 2500 else (1, 1))
+        assert model._split_keeps_bits(B) == splits and 2 * model.SPLIT_MIN_HALF <= B <= model._split_cap()
+        got = model(q).clone()
+        assert hasattr(model, "_split_stream") == splits
+        model.SPLIT_FORWARD = False
+        want = model(q).clone()
+        model.SPLIT_FORWARD = True
+        assert torch.equal(got, want)
+        (fb,) = [o.clone() for o in model.forward_batches(iter([q]), stable_inputs=True)]
+        assert torch.equal(fb, want)
+        # what the rule protects against: the two implementations are NOT promised to agree bit for bit
+        e.set_option("fused_head", 2 if C == 2500 else 0)
+        other = model._forward_on(e, q).clone()
+        e.set_option("fused_head", 1)
+        assert float((other - want).abs().max()) < 2e-3
+        del model
+    torch.cuda.empty_cache()

@@ -4,7 +4,9 @@ into a hipGraph, 10 replays timed with HIP events (device time per call, no per-
 import json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-if "--stamps" in sys.argv:
+if "--acqrel" in sys.argv:      # experiment build: release / acquire on the phase counters of the one-launch head (head_fused.hip hf_signal / hf_wait)
+    os.environ["OVMR_HEAD_ACQREL"] = "1"
+if "--stamps" in sys.argv or "--acqrel" in sys.argv or "--exp" in sys.argv:
     os.environ.setdefault("OVMR_HIP_LIB", os.path.join(ROOT, "ovmr_amd", "lib", "libovmr_hip_exp.so"))
 import torch
 from ovmr_amd import synth
