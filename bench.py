@@ -774,7 +774,7 @@ def shard_of_world(args, model, spec, dev, keep=None, peers=None):
     `projection` holds the N-rank figure (total images / this rank's time), which excludes xGMI, barrier skew and start-up.
     keep: a dict that receives the tensors behind the line (tests/test_hip_configs.py checks them against the oracle).
     peers: None = every other rank's exemplars go through the encoder (the bench preset); a list = only those ranks' do, the remaining
-    ranks contribute unit-norm random rows and features under their own class labels (the GPU test: what it probes on those ranks is the
+    ranks contribute one random unit direction per class as its three classifier rows and near copies of it as its features (the GPU test: what it probes on those ranks is the
     all-gather, the votes and the counters, not the encoder a third time -- 120 960 instead of 322 560 images at 5 040 classes)."""
     import torch
     from ovmr_amd.data import ResidentEvalSet
@@ -808,10 +808,14 @@ def shard_of_world(args, model, spec, dev, keep=None, peers=None):
                 a0, a1 = shard_range(C, r, N)
                 loc = torch.arange(a0, a1, device=dev)
                 sg = torch.Generator(device=dev).manual_seed(99 + r)
-                unit = lambda *shape: torch.nn.functional.normalize(torch.randn(shape, generator=sg, device=dev), dim=-1).half()
-                model.mm_classifier[loc], model.visual_classifer[loc], model._text_rows[loc] = unit(a1 - a0, D), unit(a1 - a0, D), unit(a1 - a0, D)
+                # one random unit direction per class serves as its mm / vision / text row, and its S "exemplar features" are that direction
+                # plus a little noise: every vote of these ranks goes to the row's own class by a wide margin (logit ~99 against |logit| < 25
+                # for every other row), and no real exemplar ever votes for them -- they exercise the all-gather, the counters and the
+                # all-reduce without adding near-tied argmaxes to the job
+                u = torch.nn.functional.normalize(torch.randn((a1 - a0, D), generator=sg, device=dev), dim=-1)
+                model.mm_classifier[loc] = model.visual_classifer[loc] = model._text_rows[loc] = u.half()
                 model.visual_tokens[loc] = torch.randn((a1 - a0, n_ctx, D), generator=sg, device=dev).half()
-                model.eval_feat4cls[loc] = unit(a1 - a0, S, D)
+                model.eval_feat4cls[loc] = torch.nn.functional.normalize(u[:, None, :] + 0.01 * torch.randn((a1 - a0, S, D), generator=sg, device=dev), dim=-1).half()
                 blocks[r] = pack_block(torch.cat([model.mm_classifier[loc], model.visual_classifer[loc], model._text_rows[loc],
                                                   model.visual_tokens[loc].flatten(1)], dim=1), loc, bound)
                 continue

@@ -49,6 +49,7 @@ def main():
         loader = [{"img": img[s:s + 3 * S], "label": torch.from_numpy(labels[s:s + 3 * S])} for s in range(0, C * S, 3 * S)]
     q = torch.from_numpy(synth.images(5, spec.image_resolution, 777))
     out = model(q, eval_set_loader=loader)
+    model.wait_files()                        # (the first forward generated the classifiers: rank 0's files are written behind its back)
     torch.cuda.synchronize()
     devices_seen, rccl_version = None, None
     if dist.is_initialized():
