@@ -6,7 +6,7 @@
 T=${1:-r03x}; R=$(pwd)
 mkdir -p gpurun_out profiles
 if [ -z "$2" ]; then
-  timeout 3000 python -m pytest tests -m gpu -x -q > gpurun_out/${T}_pytest.log 2>&1; tail -2 gpurun_out/${T}_pytest.log
+  timeout 3000 python -m pytest tests -m gpu -q --durations=10 > gpurun_out/${T}_pytest.log 2>&1; tail -14 gpurun_out/${T}_pytest.log
   timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/${T}_smoke.log 2>&1; tail -1 gpurun_out/${T}_smoke.log
 fi
 bash tools/pmc_gemm.sh 108 gpurun_out/${T}_pmc_gemm 775 > gpurun_out/${T}_pmc_gemm.log 2>&1
@@ -16,9 +16,12 @@ cp gpurun_out/${T}_pmc_attn/summary.json profiles/${T}_pmc_attn.json
 timeout 900 python bench.py > gpurun_out/${T}_bench.log 2>&1; grep '^{"metric' gpurun_out/${T}_bench.log > profiles/${T}_bench_n1.json; cut -c1-200 profiles/${T}_bench_n1.json
 # (the default bench line above carries c2 / c3 / c4 / c5 as `presets`)  The 8-rank projection, the one-rank RCCL line and the 2-rank line
 # over gloo on this one GPU (launched exactly as the driver launches N > 1: per-rank times and the collectives in `dist`) of the same build, same box
-timeout 900 python bench.py --emulate-world 8 --no-cpu-baseline --presets 0 > gpurun_out/${T}_emu8.log 2>&1; grep '^{"metric' gpurun_out/${T}_emu8.log > profiles/${T}_emulated_world8.json
+timeout 900 python bench.py --emulate-world 8 --steps 5 --warmup 2 --no-cpu-baseline --presets 0 > gpurun_out/${T}_emu8.log 2>&1; grep '^{"metric' gpurun_out/${T}_emu8.log > profiles/${T}_emulated_world8.json
 timeout 900 python bench.py --force-dist --no-cpu-baseline --presets 0 > gpurun_out/${T}_fd.log 2>&1; grep '^{"metric' gpurun_out/${T}_fd.log > profiles/${T}_bench_n1_force_dist_rccl.json
-OVMR_DIST_BACKEND=gloo timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --steps 3 --warmup 1 > gpurun_out/${T}_gloo2.log 2>&1; grep '^{"metric' gpurun_out/${T}_gloo2.log > profiles/${T}_bench_gloo_2ranks_one_gpu.json
+for n in 2 4; do   # the driver's own N > 1 command, ranks sharing this one GPU over gloo (OVMR_DIST_BACKEND): per-rank times and the collectives in `dist`
+  OVMR_DIST_BACKEND=gloo timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node $n --master-addr 127.0.0.1 --master-port 2951$n bench.py --gpus $n --steps 3 --warmup 1 > gpurun_out/${T}_gloo$n.log 2>&1; grep '^{"metric' gpurun_out/${T}_gloo$n.log > profiles/${T}_bench_gloo_${n}ranks_one_gpu.json
+done
+timeout 300 python tools/sync_audit.py > profiles/${T}_sync_audit.log 2>&1
 timeout 600 python tools/head_bench.py > profiles/${T}_head_bench.log 2>&1
 timeout 600 python tools/attn_bench.py --variants 1 3 > profiles/${T}_attn_bench.log 2>&1
 bash tools/pmc_attn_l577.sh gpurun_out/${T}_pmc_attn_l577 > gpurun_out/${T}_pmc_attn_l577.log 2>&1; cp gpurun_out/${T}_pmc_attn_l577/summary.json profiles/${T}_pmc_attn_l577.json
