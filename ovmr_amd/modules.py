@@ -30,6 +30,38 @@ from .runtime import Engine
 from .synth import ModelSpec, SOT_ID, EOT_ID
 
 
+# ----------------------------------------------------------------------------- torch.save of host copies, tagged as the device tensors they mirror
+_LOCATION_OVERRIDE: Dict[int, int] = {}          # storage data_ptr -> index of the device its values came from
+
+
+def _override_tagger(storage):
+    """torch.serialization location tagger (register_package): storages listed in _LOCATION_OVERRIDE are written with that location --
+    "cuda:0" for the page-locked host copy of a device tensor, so that the archive equals a torch.save of the device tensor itself and
+    reloads onto the device as the reference's files do (trainers/mm_classifier_one_prompt.py:276-291 saves CUDA tensors)."""
+    if not _LOCATION_OVERRIDE:
+        return None
+    idx = _LOCATION_OVERRIDE.get(storage.data_ptr())
+    # a NEW string per storage, as torch's own tagger builds it: the pickler memoises by object identity, and one shared tag object would
+    # be written once and referenced afterwards -- other bytes than a torch.save of the device tensors
+    return None if idx is None else "cuda:" + str(idx)
+
+
+torch.serialization.register_package(1, _override_tagger, lambda storage, location: None)
+
+
+class _saved_as_on_device:
+    def __init__(self, tensors, device_index: int):
+        self.keys, self.tag = [t.untyped_storage().data_ptr() for t in tensors], int(device_index)
+
+    def __enter__(self):
+        for k in self.keys:
+            _LOCATION_OVERRIDE[k] = self.tag
+
+    def __exit__(self, *exc):
+        for k in self.keys:
+            _LOCATION_OVERRIDE.pop(k, None)
+
+
 # ----------------------------------------------------------------------------- CLIP weights
 def infer_spec(state_dict: Dict[str, torch.Tensor], name: str = "from_state_dict") -> ModelSpec:
     """Architecture inference of build_model(), clip/model.py:899-928 (ViT branch only)."""
@@ -534,9 +566,9 @@ class CustomCLIP(_TwoInFlight):
                                   # The files are the same bytes either way (tests/test_hip_parity.py::test_async_file_write_is_byte_identical).
 
     def _write_files(self):
-        """:276-291.  The saved objects are what the reference saves -- CUDA tensors, fp32 classifiers and fp16 visual tokens -- snapshotted on
-        the caller's stream; `torch.save` itself (device-to-host copies on a side stream, pickling, the zip archive) runs in a worker
-        thread.  wait_files() joins it: forward_prompt calls it before it writes again, MM_CLS_OP.test() / the CLI / bench.py's step
+        """:276-291.  The saved objects are what the reference saves -- fp32 classifiers and fp16 visual tokens tagged with the device they
+        live on -- snapshotted on the caller's stream and copied to page-locked host buffers on a side stream; `torch.save` itself
+        (pickling, the zip archive) runs in a worker thread once the copies have landed.  wait_files() joins it: forward_prompt calls it before it writes again, MM_CLS_OP.test() / the CLI / bench.py's step
         before they report, and the interpreter joins the (non-daemon) thread at exit."""
         self.wait_files()
         out_dir = self.cfg.OUTPUT_DIR
@@ -545,7 +577,7 @@ class CustomCLIP(_TwoInFlight):
               "mm_classifier": self.mm_classifier.float(),
               "fusion_weight": self.fusion_weight.float()}
 
-        def save(vt):
+        def save(mm, vt):
             # each archive is written under its own name inside a scratch directory (torch.save names the archive's records after the
             # file: the bytes are those of a direct torch.save(obj, "<OUTPUT_DIR>/mm_classifiers.pt")) and moved into place whole, so a
             # reader never finds a half-written file under the final name
@@ -561,27 +593,44 @@ class CustomCLIP(_TwoInFlight):
                 shutil.rmtree(scratch, ignore_errors=True)
 
         if not self.ASYNC_FILE_WRITE:
-            save(self.visual_tokens)
+            save(mm, self.visual_tokens.clone())             # (a copy: `visual_tokens` may be a view of a larger storage, which torch.save would write whole)
             return
         import threading
         vt = self.visual_tokens.clone()                      # (a later forward_prompt allocates new buffers, but a caller may write into this one)
         on_gpu = self.device.type == "cuda"                  # (the multi-process CPU tests drive this class with a host-side stand-in engine)
         if on_gpu:
+            # The device-to-host copies are ENQUEUED here, by the caller's thread, on a side stream, into page-locked buffers kept from
+            # job to job: an asynchronous copy returns at once.  (torch.save on the device tensors from the worker thread copies each
+            # storage into pageable memory with a blocking hipMemcpy; while those ran -- 4 ms in all for 8 MB -- the caller's kernel
+            # launches queued up behind the runtime, exactly when the GPU had just been drained by the generation's final check: a
+            # sharded rank 0 lost 4 ms of its 86 to a write that was meant to cost it nothing.)  The worker thread waits for the copies'
+            # event and pickles the HOST tensors; _saved_as_on_device makes torch.save tag their storages with the device the values
+            # came from, so the archive is byte for byte the one torch.save of the device tensors writes.
             cur = torch.cuda.current_stream(self.device)
             ready = torch.cuda.Event()
             ready.record(cur)
             if not hasattr(self, "_file_stream"):
-                self._file_stream = torch.cuda.Stream(self.device)
-            side, dev = self._file_stream, self.device
+                self._file_stream, self._file_pinned = torch.cuda.Stream(self.device), {}
+            side, copied = self._file_stream, torch.cuda.Event()
+            host = {}
+            with torch.cuda.stream(side):
+                side.wait_event(ready)
+                for name, t in list(mm.items()) + [("visual_tokens", vt)]:
+                    buf = self._file_pinned.get(name)
+                    if buf is None or buf.shape != t.shape or buf.dtype != t.dtype:
+                        buf = self._file_pinned[name] = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+                    buf.copy_(t, non_blocking=True)
+                    host[name] = buf
+                copied.record(side)
+            tag = self.device.index if self.device.index is not None else torch.cuda.current_device()
 
         def work():
             try:
                 if not on_gpu:
-                    return save(vt)
-                torch.cuda.set_device(dev)
-                with torch.cuda.stream(side):                # torch.save copies each CUDA storage to the host on the CURRENT stream of this thread
-                    side.wait_event(ready)
-                    save(vt)
+                    return save(mm, vt)
+                copied.synchronize()                         # (blocks this thread only; mm / vt stay referenced by this closure until then)
+                with _saved_as_on_device(list(host.values()), tag):
+                    save({k: host[k] for k in mm}, host["visual_tokens"])
             except BaseException as e:                       # noqa: BLE001 -- re-raised by wait_files() on the caller's thread
                 self._file_error = e
 
