@@ -553,14 +553,19 @@ class CustomCLIP(_TwoInFlight):
             all_initialized = all_initialized & (self._stray_rows == 0).all()
         self.fusion_weight = self._xval_fusion_weight(local, self.mm_classifier, self.visual_classifer,
                                                       self.zero_shot_classifier, float(self.cfg.EVAL_TAU))   # :261-274
+        # rank 0's output files: conversions and device-to-host copies are enqueued HERE, behind the head and in front of the host's one
+        # synchronisation (the host is still ahead of the GPU: nothing of it lands on the critical path); the writer starts once the check
+        # has passed (the reference asserts before it saves, :259 / :276)
+        writer = self._write_files() if rank == 0 and self.cfg.OUTPUT_DIR else None
         assert bool(all_initialized), "a class received no exemplar batch"          # :259
-        if rank == 0 and self.cfg.OUTPUT_DIR:
-            self._write_files()
+        if writer is not None:
+            writer()
             if wait_files:
                 self.wait_files()
         return self.mm_classifier, self.visual_classifer, self.fusion_weight
 
     # ------------------------------------------------------------------ the two output files, off the critical path
+    FILE_WRITE_DELAY_S = 0.05     # the writer thread starts its work when wait_files() is called, or this long after the job (see _write_files)
     ASYNC_FILE_WRITE = True       # mm_classifiers.pt / visual_tokens.pt (:276-291) are written by a worker thread behind a side stream while the
                                   # caller goes on (the query loop of a test pass, the next rank's barrier); False: inline, as the reference does.
                                   # The files are the same bytes either way (tests/test_hip_parity.py::test_async_file_write_is_byte_identical).
@@ -568,7 +573,8 @@ class CustomCLIP(_TwoInFlight):
     def _write_files(self):
         """:276-291.  The saved objects are what the reference saves -- fp32 classifiers and fp16 visual tokens tagged with the device they
         live on -- snapshotted on the caller's stream and copied to page-locked host buffers on a side stream; `torch.save` itself
-        (pickling, the zip archive) runs in a worker thread once the copies have landed.  wait_files() joins it: forward_prompt calls it before it writes again, MM_CLS_OP.test() / the CLI / bench.py's step
+        (pickling, the zip archive) runs in a worker thread once the copies have landed.  Returns the callable that starts the writer
+        (forward_prompt calls it once its completeness check has passed).  wait_files() joins it: forward_prompt calls it before it writes again, MM_CLS_OP.test() / the CLI / bench.py's step
         before they report, and the interpreter joins the (non-daemon) thread at exit."""
         self.wait_files()
         out_dir = self.cfg.OUTPUT_DIR
@@ -593,8 +599,8 @@ class CustomCLIP(_TwoInFlight):
                 shutil.rmtree(scratch, ignore_errors=True)
 
         if not self.ASYNC_FILE_WRITE:
-            save(mm, self.visual_tokens.clone())             # (a copy: `visual_tokens` may be a view of a larger storage, which torch.save would write whole)
-            return
+            vt_now = self.visual_tokens.clone()              # (a copy: `visual_tokens` may be a view of a larger storage, which torch.save would write whole)
+            return lambda: save(mm, vt_now)
         import threading
         vt = self.visual_tokens.clone()                      # (a later forward_prompt allocates new buffers, but a caller may write into this one)
         on_gpu = self.device.type == "cuda"                  # (the multi-process CPU tests drive this class with a host-side stand-in engine)
@@ -624,25 +630,37 @@ class CustomCLIP(_TwoInFlight):
                 copied.record(side)
             tag = self.device.index if self.device.index is not None else torch.cuda.current_device()
 
+        go = threading.Event()
+
         def work():
             try:
                 if not on_gpu:
                     return save(mm, vt)
+                # The writer yields to the caller's launch loop: it starts its CPU work (waiting on the copies' event, pickling, 8 MB of
+                # CRC and tmpfs writes) when the caller asks for the files (wait_files sets `go`) or FILE_WRITE_DELAY_S after the job, whichever
+                # comes first.  Started at once, it cost a sharded rank 0 between 0.9 and 2.6 ms of its 86 (two passes on one box,
+                # profiles/r06h_*): the first milliseconds after a generation are when the host enqueues the query batches, and a second busy
+                # thread in the process slows exactly that; by the time anybody waits for the files the GPU has its work queued.
+                go.wait(self.FILE_WRITE_DELAY_S)
                 copied.synchronize()                         # (blocks this thread only; mm / vt stay referenced by this closure until then)
                 with _saved_as_on_device(list(host.values()), tag):
                     save({k: host[k] for k in mm}, host["visual_tokens"])
             except BaseException as e:                       # noqa: BLE001 -- re-raised by wait_files() on the caller's thread
                 self._file_error = e
 
-        self._file_error = None
-        self._file_thread = threading.Thread(target=work, name="ovmr-classifier-files", daemon=False)
-        self._file_thread.start()
+        def start():
+            self._file_error, self._file_go = None, go
+            self._file_thread = threading.Thread(target=work, name="ovmr-classifier-files", daemon=False)
+            self._file_thread.start()
+
+        return start
 
     def wait_files(self):
         """Returns once the classifier files of the last forward_prompt are complete on disk (no-op when nothing is in flight); raises what
         the writer raised."""
         t = getattr(self, "_file_thread", None)
         if t is not None:
+            self._file_go.set()
             t.join()
             self._file_thread = None
             err, self._file_error = getattr(self, "_file_error", None), None
