@@ -49,12 +49,13 @@ __device__ __forceinline__ void fq_glds16(const void* gsrc, unsigned lds_dst) {
 
 __device__ __forceinline__ int fq_swz(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
 
+template <bool PP>                                      // PP: the ping-pong K loop (OVMR_FQ_ABL bit 16) -- its own instantiation, its own register allocation
 __global__ __launch_bounds__(512) void qkv_attn_fused_kernel(const half_t* __restrict__ x, const half_t* __restrict__ wf,
                                                               const float* __restrict__ ln_g, const float* __restrict__ ln_b,
                                                               const float* __restrict__ stats, half_t* __restrict__ out,
                                                               int B, int L, int W, int H, float scale_log2e, int abl) {
     // abl (timing-only ablations, OVMR_FQ_ABL): 1 no phase B, 2 no MFMAs in the K loop, 4 no operand loads after a pair's first two tiles,
-    // 8 no epilogue
+    // 8 no epilogue, 16 the ping-pong K loop
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -133,6 +134,63 @@ __global__ __launch_bounds__(512) void qkv_attn_fused_kernel(const half_t* __res
         for (int i = 0; i < 7; ++i)
 #pragma unroll
             for (int j = 0; j < 3; ++j) acc[i][j] = (float4_t){0.f, 0.f, 0.f, 0.f};
+        if constexpr (PP) {
+            // ---- ping-pong form (OVMR_FQ_ABL bit 16): the two wave rows run one slot apart -- while row 0 issues the MFMAs of half-step h,
+            // row 1 reads the fragments of h, and vice versa -- so that LDS fragment traffic and matrix-pipe time overlap instead of adding
+            // (they are 7.9 and 8.6 us per pair in lockstep).  Two barriers per half-step (X, Y); the K-tile bookkeeping rides on Y of a
+            // tile's second half-step: tile kt + 1 is waited for BEFORE it (so Y publishes it), tile kt + 3 is issued AFTER it (every read
+            // of tile kt is done) -- three tiles resident or in flight.
+            half8_t fa[7], fb[3];
+            auto R = [&](int hh) {
+                const int kt = hh >> 1, ks = hh & 1;
+                const char* sA = smem + (kt % 3) * FQ_STAGE;
+                const char* sB = sA + FQ_A_BYTES;
+#pragma unroll
+                for (int i = 0; i < 7; ++i)
+                    if (i < tm_n) fa[i] = *(const half8_t*)(sA + fq_swz((tm0 + i) * 16 + fr, ks * 4 + fg));
+#pragma unroll
+                for (int j = 0; j < 3; ++j) fb[j] = *(const half8_t*)(sB + fq_swz((wn * 3 + j) * 16 + fr, ks * 4 + fg));
+            };
+            auto M = [&]() {
+#pragma unroll
+                for (int i = 0; i < 7; ++i)
+                    if (i < tm_n) {
+#pragma unroll
+                        for (int j = 0; j < 3; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+                    }
+            };
+            auto wait_tile = [&](int kt) {                          // tile kt + 1 has landed for this wave (tile kt + 2 may still be in flight)
+                if (kt + 2 >= nk) __builtin_amdgcn_s_waitcnt(0x0F70);
+                else if (wave < 2) __builtin_amdgcn_s_waitcnt(0x0F77);
+                else __builtin_amdgcn_s_waitcnt(0x0F76);
+            };
+            __builtin_amdgcn_s_waitcnt(0x0F70);                     // tiles 0 and 1 (and phase B's stores) are back
+            __syncthreads();
+            if (2 < nk) stage(2, b, h, 2);
+            for (int hh = 0; hh < 2 * nk; ++hh) {
+                const int kt = hh >> 1, ks = hh & 1;
+                if (wm == 0) {
+                    R(hh);
+                    __builtin_amdgcn_sched_barrier(0);
+                    __builtin_amdgcn_s_barrier();                   // X
+                    __builtin_amdgcn_sched_barrier(0);
+                    M();
+                } else {
+                    if (hh > 0) M();
+                    __builtin_amdgcn_sched_barrier(0);
+                    __builtin_amdgcn_s_barrier();                   // X
+                    __builtin_amdgcn_sched_barrier(0);
+                    R(hh);
+                    __builtin_amdgcn_s_waitcnt(0xC07F);             // lgkmcnt(0): the reads are back before Y lets anybody overwrite the stage
+                }
+                if (ks && kt + 1 < nk) wait_tile(kt);
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();                       // Y
+                __builtin_amdgcn_sched_barrier(0);
+                if (ks && kt + 3 < nk) stage(kt % 3, b, h, kt + 3);
+            }
+            if (wm == 1) M();
+        } else
         for (int kt = 0; kt < nk; ++kt) {
             // K-tile kt has landed for this wave: everything older than the pieces of tile kt + 1 (7 per wave for waves 0 / 1, 6 for the
             // others) is back.  The first tile of a pair waits for everything: phase B's stores and the constants' loads sit in between.
@@ -238,14 +296,19 @@ int launch_qkv_attn_fused(const half_t* x, const half_t* wf, const float* ln_g, 
     HIP_CHECK_RET(hipGetDevice(&dev));
     if (dev < 0 || dev >= OVMR_MAX_DEVICES) return -100;
     if (!attr_set[dev]) {
-        HIP_CHECK_RET(hipFuncSetAttribute((const void*)qkv_attn_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FQ_LDS));
+        HIP_CHECK_RET(hipFuncSetAttribute((const void*)qkv_attn_fused_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, FQ_LDS));
+        HIP_CHECK_RET(hipFuncSetAttribute((const void*)qkv_attn_fused_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, FQ_LDS));
         HIP_CHECK_RET(hipDeviceGetAttribute(&n_cu[dev], hipDeviceAttributeMultiprocessorCount, dev));
         attr_set[dev] = true;
     }
     const int grid = std::max(8, n_cu[dev] / 8 * 8);
     static const int abl = getenv("OVMR_FQ_ABL") ? atoi(getenv("OVMR_FQ_ABL")) : 0;
-    hipLaunchKernelGGL(qkv_attn_fused_kernel, dim3((unsigned)grid), dim3(512), FQ_LDS, s, x, wf, ln_g, ln_b, stats, out, B, L, W, W / 64,
-                       0.125f * 1.4426950408889634f, abl);
+    if (abl & 16)
+        hipLaunchKernelGGL(qkv_attn_fused_kernel<true>, dim3((unsigned)grid), dim3(512), FQ_LDS, s, x, wf, ln_g, ln_b, stats, out, B, L, W, W / 64,
+                           0.125f * 1.4426950408889634f, abl);
+    else
+        hipLaunchKernelGGL(qkv_attn_fused_kernel<false>, dim3((unsigned)grid), dim3(512), FQ_LDS, s, x, wf, ln_g, ln_b, stats, out, B, L, W, W / 64,
+                           0.125f * 1.4426950408889634f, abl);
     return (int)hipGetLastError();
 }
 
