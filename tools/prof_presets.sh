@@ -4,7 +4,7 @@
 T=${1:-r03r}; R=$(pwd)
 mkdir -p gpurun_out/${T}_keep
 cd /tmp; export TMPDIR=/tmp
-for p in c2 c3 c4 c5; do
+for p in c1 c2 c3 c4 c5; do
   extra=""; [ $p = c5 ] && extra="--steps 1 --warmup 1"; [ $p = c4 ] && extra="--steps 2 --warmup 1"
   timeout 1200 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${T}_stats_$p -- python3 $R/bench.py --preset $p --no-cpu-baseline --presets 0 $extra > $R/gpurun_out/${T}_stats_$p.log 2>&1
   f=$(find $R/gpurun_out/${T}_stats_$p -name "*kernel_stats.csv" | head -1)
