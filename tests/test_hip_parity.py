@@ -376,6 +376,18 @@ def test_async_file_write_is_byte_identical(golden, tmp_path):
     saved = torch.load(os.path.join(d2, "mm_classifiers.pt"))                # no map_location: tensors come back on the device they were saved from
     assert all(v.is_cuda and v.dtype == torch.float32 for v in saved.values())
     assert torch.load(os.path.join(d2, "visual_tokens.pt"))["visual_tokens"].is_cuda
+    # nobody asks for the files: the writer starts by itself FILE_WRITE_DELAY_S after the job (it yields to the caller's launch loop first)
+    import time
+    m3, d3 = make("unasked", True)
+    m3.FILE_WRITE_DELAY_S = 0.2
+    m3(q, eval_set_loader=loader)
+    torch.cuda.synchronize()
+    assert not os.path.exists(os.path.join(d3, "mm_classifiers.pt"))            # (0.2 s have not passed)
+    deadline = time.time() + 10.0
+    while time.time() < deadline and not os.path.exists(os.path.join(d3, "visual_tokens.pt")):
+        time.sleep(0.05)
+    m3.wait_files()
+    assert sorted(os.listdir(d3)) == sorted(names) and digest(d3) == want
     # a second job into the same directory replaces the files atomically and leaves no temporaries behind
     m2.forward_prompt(loader, wait_files=False)
     m2.wait_files()
