@@ -81,6 +81,7 @@ def parse(argv=None):
     ap.add_argument("--overlap", type=int, default=-1, help="two query batches in flight on two streams (CustomCLIP.forward_batches): "
                     "1 / 0 force it on / off, -1 = the module's rule (batches of at most 384 images); 2 / 3: the reference's unchanged test loop "
                     "instead -- model(input) per batch + a host sync per batch -- with forward() splitting a batch over two handles (2) or not (3)")
+    ap.add_argument("--in-flight", type=int, default=0, help="query batches in flight in the test loop (0: the module's default, CustomCLIP.IN_FLIGHT = 2)")
     ap.add_argument("--classes-per-batch", type=int, default=DEFAULT_CLASSES_PER_BATCH,
                     help="classes per eval-set loader batch: the whole 1000-class exemplar set arrives as one batch, the engine encodes it "
                          "--batch images at a time and the classifier head runs once (r03y: 775 / 1000 against 768 / 240: +1.5-2 % end to end)")
@@ -225,7 +226,8 @@ def main():
 
     infer_only = PRESETS[args.preset].get("value") == "inference"    # c3: the classifiers are set-up, the step is the query loop
     if args.overlap in (1, 2) or (args.overlap < 0 and args.query_batch <= model.OVERLAP_MAX_BATCH):
-        model._twin()                                   # set-up, like the first handle's: the second handle forward_batches uses (not part of a step)
+        for slot in range(1, max(2, model.IN_FLIGHT)):
+            model._twin(slot)                           # set-up, like the first handle's: the further handles forward_batches uses (not part of a step)
 
     def generate():
         if not sharded and not args.stream_text:
@@ -511,6 +513,8 @@ def make_model(args, dev, sharded=False, output_dir=""):
                                reserve=(args.batch, max(256, min(C, 2048)), max(C, 1024)), distributed=sharded,
                                stream_text=bool(args.stream_text))
     eng = model.engine
+    if getattr(args, "in_flight", 0) > 0:
+        model.IN_FLIGHT = args.in_flight
     eng.set_option("gelu_exact", args.gelu_exact)
     eng.set_option("fuse_im2col", args.fuse_im2col)
     eng.set_option("enc_chunk", args.enc_chunk)

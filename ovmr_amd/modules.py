@@ -309,11 +309,14 @@ class _TwoInFlight:
     def OVERLAP_MAX_BATCH(self, n: int):
         self._overlap_max_batch = int(n)
 
-    def _twin(self) -> Engine:
-        """A second handle: the same weights and options, its own workspace (sized for OVERLAP_MAX_BATCH images), used from
-        a second stream.  Rebuilt when the first handle's weights have changed since."""
+    IN_FLIGHT = 2                 # test batches in flight in forward_batches / inference_batches: one handle + stream each
+
+    def _twin(self, slot: int = 1) -> Engine:
+        """Handle number `slot` (1 ... IN_FLIGHT - 1; 0 is the engine itself): the same weights and options, its own workspace (sized for
+        OVERLAP_MAX_BATCH images), used from its own stream.  Rebuilt when the first handle's weights have changed since."""
         e = self.engine
-        t = getattr(self, "_twin_engine", None)
+        twins = self.__dict__.setdefault("_twin_engines", {})
+        t = twins.get(slot)
         if t is None or t._twin_of_version != e._weights_version:
             t = Engine(e.spec, e.n_ctx, str(e.device))
             t.load_state_dict(*self._twin_state())
@@ -321,7 +324,9 @@ class _TwoInFlight:
             res = getattr(e, "_reserve", (256, 256, 1024))
             t._reserve = (min(res[0], self.OVERLAP_MAX_BATCH), res[1], res[2])
             t._twin_of_version = e._weights_version
-            self._twin_engine = t
+            twins[slot] = t
+            if slot == 1:
+                self._twin_engine = t
         for k, v in e._options.items():
             if t._options.get(k) != v:
                 t.set_option(k, v)
@@ -344,27 +349,29 @@ class _TwoInFlight:
                 cur.wait_stream(st)
 
     def _forward_batches(self, batches, overlap, stable_inputs, cap, cur, hand_over):
-        pending = None                                   # (output, event on its stream)
+        import collections
+        n = max(2, int(self.IN_FLIGHT))
+        pending = collections.deque()                    # (output, event on its stream), oldest first: at most n - 1 while the next is enqueued
         k = 0
         for image in batches:
             image = self.engine._dev(image)
             use = overlap if overlap is not None else image.shape[0] <= cap
             if not use or image.shape[0] > cap:
-                if pending is not None:
-                    yield hand_over(pending)
-                    pending = None
+                while pending:
+                    yield hand_over(pending.popleft())
                 yield self._forward_on(self.engine, image)
                 continue
-            if not hasattr(self, "_overlap_streams"):
-                self._overlap_streams = [torch.cuda.Stream(self.device), torch.cuda.Stream(self.device)]
-                self._overlap_staging = [None, None]
-            eng = self.engine if (k & 1) == 0 else self._twin()
-            st = self._overlap_streams[k & 1]
-            if not stable_inputs:                        # (the previous user of this staging buffer, batch k - 2, was handed over already:
-                buf = self._overlap_staging[k & 1]       #  the current stream is ordered behind it)
+            if len(getattr(self, "_overlap_streams", ())) < n:
+                self._overlap_streams = [torch.cuda.Stream(self.device) for _ in range(n)]
+                self._overlap_staging = [None] * n
+            slot = k % n
+            eng = self.engine if slot == 0 else self._twin(slot)
+            st = self._overlap_streams[slot]
+            if not stable_inputs:                        # (the previous user of this staging buffer, batch k - n, was handed over already:
+                buf = self._overlap_staging[slot]        #  the current stream is ordered behind it)
                 if buf is None or buf.shape[1:] != image.shape[1:] or buf.shape[0] < image.shape[0] or buf.dtype != image.dtype:
-                    buf = self._overlap_staging[k & 1] = torch.empty((cap,) + tuple(image.shape[1:]),
-                                                                     dtype=image.dtype, device=self.device)
+                    buf = self._overlap_staging[slot] = torch.empty((cap,) + tuple(image.shape[1:]),
+                                                                    dtype=image.dtype, device=self.device)
                 staged = buf[:image.shape[0]]
                 staged.copy_(image)
                 image = staged
@@ -375,12 +382,12 @@ class _TwoInFlight:
                 ev.record(st)
             if stable_inputs:
                 image.record_stream(st)
-            if pending is not None:
-                yield hand_over(pending)
-            pending = (out, ev)
+            pending.append((out, ev))
+            if len(pending) >= n:
+                yield hand_over(pending.popleft())
             k += 1
-        if pending is not None:
-            yield hand_over(pending)
+        while pending:
+            yield hand_over(pending.popleft())
 
 
 # ----------------------------------------------------------------------------- CustomCLIP
