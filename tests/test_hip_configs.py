@@ -485,3 +485,19 @@ def test_forward_split_keeps_the_unsplit_head_implementation():
         assert float((other - want).abs().max()) < 2e-3
         del model
     torch.cuda.empty_cache()
+
+
+def test_config_c1_zeroshot_bench_line():
+    """BASELINE.json configuration 1 as `bench.py --preset c1` runs it (trainers/zsclip.py:32-60 on ViT-B/16, ten prompts): the line's
+    fields, the evaluator's invariants on the device-counted test pass, and the logits of the timed loop against a plain model_inference."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    args = bench.parse(["--preset", "c1", "--queries", "640", "--steps", "1", "--warmup", "1", "--no-cpu-baseline"])
+    assert (args.model, args.classes, args.query_batch) == ("ViT-B/16", 10, 256)
+    line = bench.zeroshot_config(args, torch.device("cuda:0"))
+    assert line["unit"] == "images/s" and line["value"] > 0 and line["dtype"] == "f16" and line["config"]["preset"] == "c1"
+    assert line["config"]["images_per_step"] == 640 and line["config"]["inference_batches_in_flight"] == 2
+    r = line["roofline"]
+    assert r["bound"] == "mfma" and 0.0 < r["frac"] < 1.0 and abs(r["achieved"] / r["peak"] - r["frac"]) < 1e-3
+    assert 0.0 <= line["phases"]["accuracy_of_random_labels"] <= 100.0 and line["cpu_baseline"] is None
+    torch.cuda.empty_cache()
