@@ -522,3 +522,30 @@ def test_eval_ovmr_script_maps_the_reference_directories(tmp_path):
     assert r.returncode == 0 and "results exist" in r.stdout
     r = subprocess.run(["bash", script, "caltech101"], env=env, capture_output=True, text=True)
     assert r.returncode == 2 and "usage" in r.stderr
+
+
+def test_upload_ring_asks_dev_shm_before_it_allocates(monkeypatch):
+    """The pipelined loader's upload ring lives in /dev/shm (576 MiB at batch 256 x 3 slots x 768 KiB).  SharedMemory only ftruncate()s,
+    which tmpfs grants beyond its free space -- the workers would find out with SIGBUS.  The pool asks for the free space first: too
+    little halves the share per image down to one crop, and below that the loader says what to change (no worker is started)."""
+    from ovmr_amd import loader
+    free = {"bytes": 40 << 20}
+    monkeypatch.setattr(loader, "_shm_free_bytes", lambda: free["bytes"])
+    seen = []
+    real_pool = loader._Pool
+
+    class Probe(real_pool):
+        def __init__(self, key):
+            seen.append(key[4])                                          # the share per image this attempt asks for
+            real_pool.__init__(self, key)                                # raises OSError before anything is allocated or started
+
+    monkeypatch.setattr(loader, "_Pool", Probe)
+    ld = loader.PipelinedFolderLoader([("a.jpg", 0)] * 8, 256, 224, workers=2, prefetch=3, device="cpu")
+    with pytest.raises(OSError, match="does not fit"):
+        ld._pool()
+    crop = 224 * 224 * 3
+    assert seen[0] == 768 * 1024 and seen[-1] == crop and all(a > b for a, b in zip(seen, seen[1:]))
+    assert not loader._POOLS
+    # the message names the ring and /dev/shm
+    with pytest.raises(OSError, match="/dev/shm"):
+        real_pool((2, 3, 256, 224, crop, 8, "bicubic", False))
