@@ -186,7 +186,15 @@ def main():
             dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world, timeout=to)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world, timeout=to)
-        dist_info = process_group_identity(dist, dev, backend, world)
+        try:
+            dist_info = process_group_identity(dist, dev, backend, world)      # the job's first collectives: the process group's canary
+        except RuntimeError as e:
+            # one line per failing rank, a non-zero exit, no retry: the launcher ends the job.  The usual suspects are named -- this is the
+            # point where a mis-set IPC mode or ranks doubled up on a device show
+            print(f"bench.py: rank {rank} of {world}: the process group's first collective failed over {backend}: {str(e).splitlines()[0][:300]} "
+                  f"(HSA_ENABLE_IPC_MODE_LEGACY={os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY')}, device {dev}, "
+                  f"HIP_VISIBLE_DEVICES={os.environ.get('HIP_VISIBLE_DEVICES', '<unset>')})", file=sys.stderr, flush=True)
+            sys.exit(3)
 
     if PRESETS[args.preset].get("value") == "zeroshot":
         assert world == 1 and not sharded, "--preset c1 is a one-GPU line (N ranks would run N replicas of the test loop)"
