@@ -501,3 +501,63 @@ def test_config_c1_zeroshot_bench_line():
     assert r["bound"] == "mfma" and 0.0 < r["frac"] < 1.0 and abs(r["achieved"] / r["peak"] - r["frac"]) < 1e-3
     assert 0.0 <= line["phases"]["accuracy_of_random_labels"] <= 100.0 and line["cpu_baseline"] is None
     torch.cuda.empty_cache()
+
+
+def test_generation_synchronises_with_the_host_once(tmp_path):
+    """A host synchronisation in the middle of hot loop A is a bubble for everything enqueued behind it (round 6: `buffer[index] = 1` copied its
+    scalar from pageable memory in front of ~50 launches of the sharded head -- 0.9 ms of gaps per rank).  With a device-resident exemplar set
+    one generation job -- one process, and as rank 1 of 4 through the sharded path with the collectives served from recorded blocks --
+    makes the host wait exactly once: the completeness check at its end (trainers/mm_classifier_one_prompt.py:259).  torch's sync debug mode
+    reports every call that waits."""
+    import warnings
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    from ovmr_amd import modules
+    from ovmr_amd.data import ResidentEvalSet
+    from ovmr_amd.shard import shard_range, local_class_bound
+    spec, sd, pl, cm = _small_clip("small")
+    C, S, D = 16, 4, spec.embed_dim
+    tok = torch.from_numpy(synth.class_token_ids(C, seed=3))
+    cfg = modules.make_cfg(n_ctx=2, num_shots=S, output_dir=str(tmp_path))
+    model = modules.CustomCLIP(cfg, tok, cm, prompt_learner_state={k: torch.from_numpy(x) for k, x in pl.items()}, reserve=(64, 64, 64), stream_text=True)
+    g = torch.Generator(device="cuda").manual_seed(4)
+    ex = torch.randn((C * S, 3, spec.image_resolution, spec.image_resolution), generator=g, device="cuda").half()
+    q = torch.randn((8, 3, spec.image_resolution, spec.image_resolution), generator=g, device="cuda").half()
+
+    def syncs(fn):
+        fn()                                                                   # warm-up: lazy module loads, first-use allocations
+        torch.cuda.synchronize()
+        torch.cuda.set_sync_debug_mode("warn")
+        try:
+            with warnings.catch_warnings(record=True) as w:
+                warnings.simplefilter("always")
+                fn()
+        finally:
+            torch.cuda.set_sync_debug_mode("default")
+        return [str(x.message) for x in w if "synchroniz" in str(x.message).lower() and "prototype" not in str(x.message).lower()]
+
+    whole = ResidentEvalSet(ex, torch.arange(C, device="cuda"), S, 8, presharded=True)
+
+    def job():
+        model.forward_prompt(whole, wait_files=False)
+        model(q)
+        model.wait_files()
+
+    found = syncs(job)
+    assert len(found) == 1, found
+    # rank 1 of 4 through the sharded path (the collectives served on the device: bench.EmulatedPeers)
+    c0, c1 = shard_range(C, 1, 4)
+    emu = bench.EmulatedPeers(1, 4)
+    bound = local_class_bound(C, 4, True, 1)
+    emu.peer_blocks = torch.zeros((4 * bound, 5 * D + 2), dtype=torch.float16, device="cuda")
+    lab = torch.full((4 * bound,), -1, dtype=torch.int32, device="cuda")
+    for r in range(4):
+        r0, r1 = shard_range(C, r, 4)
+        lab[r * bound:r * bound + (r1 - r0)] = torch.arange(r0, r1, dtype=torch.int32, device="cuda")
+    emu.peer_blocks[:, -2:] = lab.view(torch.float16).reshape(-1, 2)
+    emu.peer_counts = torch.zeros((3, 2, C), dtype=torch.int32, device="cuda")
+    model._dist, model._text_streamed = emu, True
+    shard = ResidentEvalSet(ex[c0 * S:c1 * S], torch.arange(c0, c1, device="cuda"), S, 8, presharded=True)
+    found = syncs(lambda: (model.forward_prompt(shard, wait_files=False), model(q)))
+    model._dist = None
+    assert len(found) == 1, found
