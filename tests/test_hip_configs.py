@@ -545,6 +545,18 @@ def test_generation_synchronises_with_the_host_once(tmp_path):
 
     found = syncs(job)
     assert len(found) == 1, found
+    # the test loop itself -- forwards two in flight, every batch counted by the evaluator on the device -- never waits; evaluate() reads once
+    from ovmr_amd.evaluator import Classification
+    ev = Classification(C, device="cuda")
+    labels = torch.randint(0, C, (32,), generator=g, device="cuda")
+    batches = [torch.randn((8, 3, spec.image_resolution, spec.image_resolution), generator=g, device="cuda").half() for _ in range(4)]
+
+    def loop():
+        for i, out in enumerate(model.forward_batches(iter(batches), stable_inputs=True)):
+            ev.process(out, labels[8 * i:8 * i + 8])
+
+    assert syncs(loop) == []
+    assert len(syncs(lambda: ev.counts())) == 1
     # rank 1 of 4 through the sharded path (the collectives served on the device: bench.EmulatedPeers)
     c0, c1 = shard_range(C, 1, 4)
     emu = bench.EmulatedPeers(1, 4)
