@@ -49,8 +49,11 @@ __device__ __forceinline__ void fq_glds16(const void* gsrc, unsigned lds_dst) {
 
 __device__ __forceinline__ int fq_swz(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
 
-template <bool PP>                                      // PP: the ping-pong K loop (OVMR_FQ_ABL bit 16) -- its own instantiation, its own register allocation
-__global__ __launch_bounds__(512) void qkv_attn_fused_kernel(const half_t* __restrict__ x, const half_t* __restrict__ wf,
+// NWV: waves per workgroup -- 8 (2 wave rows x 4 wave columns: (7 | 6) x 3 accumulator tiles per wave, two waves per SIMD) or 16 (4 x 4:
+// (4 | 3 | 3 | 3) x 3 tiles, four waves per SIMD: more fragment reads per MFMA, but other waves' reads and loads under every wave's MFMAs, and
+// the 13 query tiles of phase B in ONE round).  PP: the ping-pong K loop (8 waves only; OVMR_FQ_ABL bit 16).  HP4: pairs dealt in passes of 4 heads.
+template <int NWV, bool PP, bool HP4>
+__global__ __launch_bounds__(NWV * 64) void qkv_attn_fused_kernel(const half_t* __restrict__ x, const half_t* __restrict__ wf,
                                                               const float* __restrict__ ln_g, const float* __restrict__ ln_b,
                                                               const float* __restrict__ stats, half_t* __restrict__ out,
                                                               int B, int L, int W, int H, float scale_log2e, int abl) {
@@ -59,10 +62,11 @@ __global__ __launch_bounds__(512) void qkv_attn_fused_kernel(const half_t* __res
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    constexpr int NT_THREADS = NWV * 64, WM = NWV / 4, TMX = (FQ_NT + WM - 1) / WM;   // wave rows; row tiles of the first wave row (7 | 4)
     const int wm = wave >> 2, wn = wave & 3;
     const int fr = lane & 15, fg = lane >> 4;
     const int srow = lane >> 3, schunk = ((lane & 7) ^ srow) * 8;
-    const int tm0 = wm * 7, tm_n = wm == 0 ? 7 : 6;                 // 13 row tiles of 16: 7 + 6
+    const int tm0 = wm * (FQ_NT / WM) + min(wm, FQ_NT % WM), tm_n = FQ_NT / WM + (wm < FQ_NT % WM ? 1 : 0);   // 13 row tiles: 7 + 6, or 4 + 3 + 3 + 3
     const int nk = W / 64, slots = W / 256;
     const unsigned lds_base = (unsigned)(uintptr_t)(lptr_t)smem;
     float* col_c = (float*)(smem + FQ_CONST);                       // [0..191] = ln_g, [192..383] = ln_b of the head's columns
@@ -76,6 +80,12 @@ __global__ __launch_bounds__(512) void qkv_attn_fused_kernel(const half_t* __res
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, per_xcd = gridDim.x >> 3, ipg = per_xcd / HP;
     const int n_img_x = (B - xcd + 7) / 8, groups = (n_img_x + ipg - 1) / ipg;                // images of this XCD, groups of ipg images
     auto pair_of = [&](int it, int& b, int& h) {                     // wave-uniform; pairs past the end: b >= B
+        if constexpr (!HP4) {                                        // image-major: the 12 heads of an image on one XCD, one after the other
+            const int q = slot + it * per_xcd;
+            b = xcd + 8 * (q / H);
+            h = q % H;
+            return b < B;
+        }
         const int pass = it / max(groups, 1), g = it - pass * max(groups, 1);
         const int k = g * ipg + slot / HP;
         h = pass * HP + slot % HP;
@@ -89,28 +99,43 @@ __global__ __launch_bounds__(512) void qkv_attn_fused_kernel(const half_t* __res
             if (b < B) return true;
         }
     };
-    // one K-tile of a pair into a stage: 26 A pieces (8 token rows x 128 B) + 24 B pieces (8 weight rows), dealt to the waves
-    auto stage = [&](int st, int b, int h, int kt) {
-        for (int ins = wave; ins < 50; ins += 8) {
-            const void* src;
-            unsigned dst;
+    // one K-tile of a pair into a stage: 26 A pieces (8 token rows x 128 B) + 24 B pieces (8 weight rows), dealt to the waves.  A wave's
+    // pieces are the same for every K-tile of a pair but for the K offset, so their source addresses and LDS offsets are set up ONCE per
+    // pair (the first version recomputed them per K-tile: 2 056 scalar instructions per wave and pair, and the vector multiplies with them)
+    constexpr int PMAX = (50 + NWV - 1) / NWV;
+    unsigned poff[PMAX];                                             // byte offset of this lane's 16 bytes of piece p inside x / wf, K-tile 0
+    auto pieces = [&](int b, int h) {
+#pragma unroll
+        for (int p = 0; p < PMAX; ++p) {
+            const int ins = min(wave + p * NWV, 49);
             if (ins < 26) {
                 const int r = min(ins * 8 + srow, L - 1);           // rows past the last token repeat it (finite values, masked as keys, never stored as queries)
-                src = x + ((long)b * L + r) * W + kt * 64 + schunk;
-                dst = lds_base + st * FQ_STAGE + ins * 1024;
+                poff[p] = (unsigned)((((long)b * L + r) * W + schunk) * 2);
             } else {
                 const int j = (ins - 26) * 8 + srow, part = j >> 6;
-                src = wf + ((long)part * W + h * 64 + (j & 63)) * W + kt * 64 + schunk;
-                dst = lds_base + st * FQ_STAGE + FQ_A_BYTES + (ins - 26) * 1024;
+                poff[p] = (unsigned)((((long)part * W + h * 64 + (j & 63)) * W + schunk) * 2);
             }
-            fq_glds16(src, __builtin_amdgcn_readfirstlane(dst));
+        }
+    };
+    // (scalar base + 32-bit lane offset form of the DMA, M0 = LDS address of the wave's 1 KiB piece: as gemm_f16_v5.hip issues it)
+    auto stage = [&](int st, int kt) {
+        const char* ak = (const char*)x + kt * 128;
+        const char* wk = (const char*)wf + kt * 128;
+#pragma unroll
+        for (int p = 0; p < PMAX; ++p) {
+            const int ins = wave + p * NWV;
+            if (ins >= 50) break;
+            const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + st * FQ_STAGE + (ins < 26 ? ins * 1024 : FQ_A_BYTES + (ins - 26) * 1024));
+            if (ins < 26) asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(poff[p]), "s"(ak), "s"(dst) : "memory", "m0");
+            else asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(poff[p]), "s"(wk), "s"(dst) : "memory", "m0");
         }
     };
 
     int b, h, it = -1;
     if (!next_pair(it, b, h)) return;
-    stage(0, b, h, 0);
-    stage(1, b, h, 1);
+    pieces(b, h);
+    stage(0, 0);
+    stage(1, 1);
     for (;;) {
         // ---- epilogue constants of this pair (read after the K loop: many barriers later)
         if (tid < FQ_COLS) {
@@ -129,9 +154,9 @@ __global__ __launch_bounds__(512) void qkv_attn_fused_kernel(const half_t* __res
             row_c[FQ_ROWS + r] = -rstd * mean;
         }
         // ---- phase A: K loop over three stages, two K-tiles in flight
-        float4_t acc[7][3];
+        float4_t acc[TMX][3];
 #pragma unroll
-        for (int i = 0; i < 7; ++i)
+        for (int i = 0; i < TMX; ++i)
 #pragma unroll
             for (int j = 0; j < 3; ++j) acc[i][j] = (float4_t){0.f, 0.f, 0.f, 0.f};
         if constexpr (PP) {
@@ -140,20 +165,20 @@ __global__ __launch_bounds__(512) void qkv_attn_fused_kernel(const half_t* __res
             // (they are 7.9 and 8.6 us per pair in lockstep).  Two barriers per half-step (X, Y); the K-tile bookkeeping rides on Y of a
             // tile's second half-step: tile kt + 1 is waited for BEFORE it (so Y publishes it), tile kt + 3 is issued AFTER it (every read
             // of tile kt is done) -- three tiles resident or in flight.
-            half8_t fa[7], fb[3];
+            half8_t fa[TMX], fb[3];
             auto R = [&](int hh) {
                 const int kt = hh >> 1, ks = hh & 1;
                 const char* sA = smem + (kt % 3) * FQ_STAGE;
                 const char* sB = sA + FQ_A_BYTES;
 #pragma unroll
-                for (int i = 0; i < 7; ++i)
+                for (int i = 0; i < TMX; ++i)
                     if (i < tm_n) fa[i] = *(const half8_t*)(sA + fq_swz((tm0 + i) * 16 + fr, ks * 4 + fg));
 #pragma unroll
                 for (int j = 0; j < 3; ++j) fb[j] = *(const half8_t*)(sB + fq_swz((wn * 3 + j) * 16 + fr, ks * 4 + fg));
             };
             auto M = [&]() {
 #pragma unroll
-                for (int i = 0; i < 7; ++i)
+                for (int i = 0; i < TMX; ++i)
                     if (i < tm_n) {
 #pragma unroll
                         for (int j = 0; j < 3; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[j], fa[i], acc[i][j], 0, 0, 0);
@@ -161,12 +186,12 @@ __global__ __launch_bounds__(512) void qkv_attn_fused_kernel(const half_t* __res
             };
             auto wait_tile = [&](int kt) {                          // tile kt + 1 has landed for this wave (tile kt + 2 may still be in flight)
                 if (kt + 2 >= nk) __builtin_amdgcn_s_waitcnt(0x0F70);
-                else if (wave < 2) __builtin_amdgcn_s_waitcnt(0x0F77);
-                else __builtin_amdgcn_s_waitcnt(0x0F76);
+                else if (wave < 2) __builtin_amdgcn_s_waitcnt(NWV == 8 ? 0x0F77 : 0x0F74);
+                else __builtin_amdgcn_s_waitcnt(NWV == 8 ? 0x0F76 : 0x0F73);
             };
             __builtin_amdgcn_s_waitcnt(0x0F70);                     // tiles 0 and 1 (and phase B's stores) are back
             __syncthreads();
-            if (2 < nk) stage(2, b, h, 2);
+            if (2 < nk) stage(2, 2);
             for (int hh = 0; hh < 2 * nk; ++hh) {
                 const int kt = hh >> 1, ks = hh & 1;
                 if (wm == 0) {
@@ -187,7 +212,7 @@ __global__ __launch_bounds__(512) void qkv_attn_fused_kernel(const half_t* __res
                 __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_s_barrier();                       // Y
                 __builtin_amdgcn_sched_barrier(0);
-                if (ks && kt + 3 < nk) stage(kt % 3, b, h, kt + 3);
+                if (ks && kt + 3 < nk) stage(kt % 3, kt + 3);
             }
             if (wm == 1) M();
         } else
@@ -195,23 +220,23 @@ __global__ __launch_bounds__(512) void qkv_attn_fused_kernel(const half_t* __res
             // K-tile kt has landed for this wave: everything older than the pieces of tile kt + 1 (7 per wave for waves 0 / 1, 6 for the
             // others) is back.  The first tile of a pair waits for everything: phase B's stores and the constants' loads sit in between.
             if (kt == 0 || kt + 1 >= nk) __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0)
-            else if (wave < 2) __builtin_amdgcn_s_waitcnt(0x0F77);                     // vmcnt(7)
-            else __builtin_amdgcn_s_waitcnt(0x0F76);                                   // vmcnt(6)
+            else if (wave < 2) __builtin_amdgcn_s_waitcnt(NWV == 8 ? 0x0F77 : 0x0F74); // vmcnt(7 | 4): 50 pieces over 8 | 16 waves
+            else __builtin_amdgcn_s_waitcnt(NWV == 8 ? 0x0F76 : 0x0F73);               // vmcnt(6 | 3)
             __syncthreads();                                        // ... everybody's has, and everybody is done with tile kt - 1 (and phase B)
-            if (kt + 2 < nk && !(abl & 4)) stage((kt + 2) % 3, b, h, kt + 2);
+            if (kt + 2 < nk && !(abl & 4)) stage((kt + 2) % 3, kt + 2);
             const char* sA = smem + (kt % 3) * FQ_STAGE;
             const char* sB = sA + FQ_A_BYTES;
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-                half8_t fa[7], fb[3];
+                half8_t fa[TMX], fb[3];
 #pragma unroll
-                for (int i = 0; i < 7; ++i)
+                for (int i = 0; i < TMX; ++i)
                     if (i < tm_n) fa[i] = *(const half8_t*)(sA + fq_swz((tm0 + i) * 16 + fr, ks * 4 + fg));
 #pragma unroll
                 for (int j = 0; j < 3; ++j) fb[j] = *(const half8_t*)(sB + fq_swz((wn * 3 + j) * 16 + fr, ks * 4 + fg));
                 if (abl & 2) continue;
 #pragma unroll
-                for (int i = 0; i < 7; ++i)
+                for (int i = 0; i < TMX; ++i)
                     if (i < tm_n) {
 #pragma unroll
                         for (int j = 0; j < 3; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[j], fa[i], acc[i][j], 0, 0, 0);
@@ -228,7 +253,7 @@ __global__ __launch_bounds__(512) void qkv_attn_fused_kernel(const half_t* __res
             // thirds: 0 = Q, 1 = K, 2 = V
             char* img = smem + (part == 0 ? FQ_Q : FQ_KV + (part - 1) * FQ_A_BYTES);
 #pragma unroll
-            for (int i = 0; i < 7; ++i) {
+            for (int i = 0; i < TMX; ++i) {
                 if (i >= tm_n) continue;
                 const int row = (tm0 + i) * 16 + fr;
                 const float ln_r = row_c[row], ln_t = row_c[FQ_ROWS + row];
@@ -249,27 +274,31 @@ __global__ __launch_bounds__(512) void qkv_attn_fused_kernel(const half_t* __res
         // ---- the next pair's first two K-tiles stream into S0 / S1 under phase B (S1 once every wave holds its query fragments)
         int nb, nh, nit = it;
         const bool more = next_pair(nit, nb, nh);
-        if (more) stage(0, nb, nh, 0);
-        half8_t qf[2][2];
+        if (more) {
+            pieces(nb, nh);                                  // (the K loop of this pair is over: the table now describes the next pair)
+            stage(0, 0);
+        }
+        constexpr int QR = (FQ_NT + NWV - 1) / NWV;          // rounds of query tiles in phase B: 2 with 8 waves, 1 with 16
+        half8_t qf[QR][2];
         {
             const char* sQ = smem + FQ_Q;
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const int qr = min((wave + 8 * u) * 16 + fr, FQ_ROWS - 1);
+            for (int u = 0; u < QR; ++u) {
+                const int qr = min((wave + NWV * u) * 16 + fr, FQ_ROWS - 1);
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) qf[u][ks] = *(const half8_t*)(sQ + fq_swz(qr, ks * 4 + fg));
             }
         }
         __syncthreads();
-        if (more) stage(1, nb, nh, 1);
+        if (more) stage(1, 1);
         // ---- phase B: the 13 query tiles of the head, two rounds of the 8 waves
         {
             const half_t* sK = (const half_t*)(smem + FQ_KV);
             const half_t* sV = sK + FQ_ROWS * 64;
             const int D = H * 64;
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const int t = wave + 8 * u;
+            for (int u = 0; u < QR; ++u) {
+                const int t = wave + NWV * u;
                 if (t >= FQ_NT || (abl & 1)) break;
                 const int qr = t * 16 + fr;
                 float4_t o[4];
@@ -295,20 +324,22 @@ int launch_qkv_attn_fused(const half_t* x, const half_t* wf, const float* ln_g, 
     int dev = 0;
     HIP_CHECK_RET(hipGetDevice(&dev));
     if (dev < 0 || dev >= OVMR_MAX_DEVICES) return -100;
+    typedef void (*kern_t)(const half_t*, const half_t*, const float*, const float*, const float*, half_t*, int, int, int, int, float, int);
+    static const int abl = getenv("OVMR_FQ_ABL") ? atoi(getenv("OVMR_FQ_ABL")) : 0;
+    // bit 16: ping-pong K loop (8 waves); bit 32: 16 waves per workgroup; bit 64: pairs in passes of 4 heads
+    const kern_t kern = (abl & 32) ? ((abl & 64) ? (kern_t)qkv_attn_fused_kernel<16, false, true> : (kern_t)qkv_attn_fused_kernel<16, false, false>)
+                      : (abl & 16) ? (kern_t)qkv_attn_fused_kernel<8, true, false>
+                      : (abl & 64) ? (kern_t)qkv_attn_fused_kernel<8, false, true> : (kern_t)qkv_attn_fused_kernel<8, false, false>;
     if (!attr_set[dev]) {
-        HIP_CHECK_RET(hipFuncSetAttribute((const void*)qkv_attn_fused_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, FQ_LDS));
-        HIP_CHECK_RET(hipFuncSetAttribute((const void*)qkv_attn_fused_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, FQ_LDS));
+        for (kern_t k : {(kern_t)qkv_attn_fused_kernel<16, false, true>, (kern_t)qkv_attn_fused_kernel<16, false, false>, (kern_t)qkv_attn_fused_kernel<8, true, false>,
+                         (kern_t)qkv_attn_fused_kernel<8, false, true>, (kern_t)qkv_attn_fused_kernel<8, false, false>})
+            HIP_CHECK_RET(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, FQ_LDS));
         HIP_CHECK_RET(hipDeviceGetAttribute(&n_cu[dev], hipDeviceAttributeMultiprocessorCount, dev));
         attr_set[dev] = true;
     }
     const int grid = std::max(8, n_cu[dev] / 8 * 8);
-    static const int abl = getenv("OVMR_FQ_ABL") ? atoi(getenv("OVMR_FQ_ABL")) : 0;
-    if (abl & 16)
-        hipLaunchKernelGGL(qkv_attn_fused_kernel<true>, dim3((unsigned)grid), dim3(512), FQ_LDS, s, x, wf, ln_g, ln_b, stats, out, B, L, W, W / 64,
-                           0.125f * 1.4426950408889634f, abl);
-    else
-        hipLaunchKernelGGL(qkv_attn_fused_kernel<false>, dim3((unsigned)grid), dim3(512), FQ_LDS, s, x, wf, ln_g, ln_b, stats, out, B, L, W, W / 64,
-                           0.125f * 1.4426950408889634f, abl);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3((abl & 32) ? 1024 : 512), FQ_LDS, s, x, wf, ln_g, ln_b, stats, out, B, L, W, W / 64,
+                       0.125f * 1.4426950408889634f, abl);
     return (int)hipGetLastError();
 }
 
