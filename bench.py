@@ -81,6 +81,8 @@ def parse(argv=None):
     ap.add_argument("--overlap", type=int, default=-1, help="two query batches in flight on two streams (CustomCLIP.forward_batches): "
                     "1 / 0 force it on / off, -1 = the module's rule (batches of at most 384 images); 2 / 3: the reference's unchanged test loop "
                     "instead -- model(input) per batch + a host sync per batch -- with forward() splitting a batch over two handles (2) or not (3)")
+    ap.add_argument("--fuse-qkv-attn", type=int, default=0, help="experiment build only (OVMR_HIP_LIB=.../libovmr_hip_exp.so): in_proj + attention of the vision "
+                    "blocks as one launch per block (csrc/experiments/qkv_attn_fused.hip; OVMR_FQ_ABL=32 selects its 16-wave form)")
     ap.add_argument("--in-flight", type=int, default=0, help="query batches in flight in the test loop (0: the module's default, CustomCLIP.IN_FLIGHT = 2)")
     ap.add_argument("--classes-per-batch", type=int, default=DEFAULT_CLASSES_PER_BATCH,
                     help="classes per eval-set loader batch: the whole 1000-class exemplar set arrives as one batch, the engine encodes it "
@@ -523,6 +525,8 @@ def make_model(args, dev, sharded=False, output_dir=""):
     eng = model.engine
     if getattr(args, "in_flight", 0) > 0:
         model.IN_FLIGHT = args.in_flight
+    if getattr(args, "fuse_qkv_attn", 0):
+        eng.set_option("fuse_qkv_attn", args.fuse_qkv_attn)
     eng.set_option("gelu_exact", args.gelu_exact)
     eng.set_option("fuse_im2col", args.fuse_im2col)
     eng.set_option("enc_chunk", args.enc_chunk)

@@ -14,6 +14,11 @@
 #include <string>
 #include <vector>
 
+#ifdef OVMR_EXPERIMENTS
+int launch_qkv_attn_fused(const half_t* x, const half_t* wf, const float* ln_g, const float* ln_b, const float* stats, half_t* out,
+                          int B, int L, int W, hipStream_t s);     // csrc/experiments/qkv_attn_fused.hip
+#endif
+
 namespace {
 
 struct Buf {
@@ -50,6 +55,7 @@ struct ovmr_handle {
     int xval_fused = 1;                       // cross-validation logits: row argmax fused into the GEMM epilogue (never stored)
     int fused_head = 1;                       // ovmr_fused_logits / ovmr_zeroshot_logits as ONE launch (head_fused.hip); 0: scale + GEMMs + softmax
     int head_max_grid = 0;                    // > 0 caps the fused head's grid (tests: workgroups then take several tiles)
+    int fuse_qkv_attn = 0;                    // experiment build only: in_proj + attention of the vision blocks as ONE launch per block (csrc/experiments/qkv_attn_fused.hip)
     int* head_sync = nullptr;                 // the fused head's device counters (zero between launches)
     float logit_scale_exp = 100.f;
     bool have_logit_scale = false;
@@ -211,6 +217,15 @@ int run_block_f16(ovmr_handle* h, const Block& k, half_t* x, half_t* y, half_t* 
     int M = nseq * L;
     if (groups) { M = 0; for (auto& g : *groups) M += g.nseq * g.L; }
     const int H = W / 64, slots = W / 256;
+#ifdef OVMR_EXPERIMENTS
+    if (stats && h->fuse_qkv_attn && !groups && !causal) {             // experiment: qkv never leaves the CU (bit-equal to the two launches below)
+        const int rc = launch_qkv_attn_fused(x, k.in_wf, k.in_g, k.in_bf, stats, y, nseq, L, W, s);
+        if (rc != -100) {
+            CK(rc);
+            goto attention_done;
+        }
+    }
+#endif
     if (stats) {
         CK(launch_gemm_f16(gemm_ln(gemm(x, W, k.in_wf, W, qkv, 3 * W, M, 3 * W, W, EPI_LN_BIAS), stats, slots, k.in_g, k.in_bf), h->gemm_variant, s));
     } else {
@@ -232,6 +247,9 @@ int run_block_f16(ovmr_handle* h, const Block& k, half_t* x, half_t* y, half_t* 
                 CK(launch_attention_f16(qkv + g.row0 * 3 * W, y + g.row0 * W, g.nseq, g.L, H, causal, h->attn_variant, s));
     } else
         CK(launch_attention_f16(qkv, y, nseq, L, H, causal, h->attn_variant, s));
+#ifdef OVMR_EXPERIMENTS
+attention_done:
+#endif
     CK(launch_gemm_f16(gemm_stats(gemm(y, W, k.out_w, W, x, W, M, W, W, EPI_BIAS_RES, k.out_b, x, W), stats), h->gemm_variant, s));
     if (stats) {
         CK(launch_gemm_f16(gemm_ln(gemm(x, W, k.fc_wf, W, hid, 4 * W, M, 4 * W, W, EPI_LN_BIAS_QGELU), stats, slots, k.fc_g, k.fc_bf), h->gemm_variant + (h->gelu_exact ? 0 : 100), s));
@@ -445,6 +463,9 @@ int ovmr_set_option(ovmr_handle* h, const char* key, int value) {
     else if (!strcmp(key, "fused_head")) h->fused_head = value;
     else if (!strcmp(key, "head_max_grid")) h->head_max_grid = value;
     else if (!strcmp(key, "gelu_exact")) h->gelu_exact = value;
+#ifdef OVMR_EXPERIMENTS
+    else if (!strcmp(key, "fuse_qkv_attn")) h->fuse_qkv_attn = value;
+#endif
     else return fail(h, OVMR_E_NAME, "unknown option '%s'", key);
     return 0;
 }
